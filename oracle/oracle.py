@@ -1,0 +1,119 @@
+"""TEST INFRASTRUCTURE: ctypes binding of the CPU oracles (oracle/librt_oracle.so, liboctree_oracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; it is the
+checker, never the thing measured or shipped.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_OLIB = None
+
+
+def build(force: bool = False, targets=("librt_oracle.so", "liboctree_oracle.so")) -> None:
+    targets = [t for t in targets if force or not os.path.exists(os.path.join(HERE, t))]
+    if targets:
+        r = subprocess.run(["make", "-C", HERE] + (["-B"] if force else []) + targets, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+
+
+class _Scene(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("normals", C.c_void_p), ("tri_refs", C.c_void_p), ("nodes", C.c_void_p),
+                ("n_vert", C.c_uint64), ("n_ref", C.c_uint64), ("n_words", C.c_uint64),
+                ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
+                ("sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32)]
+
+
+class _Frame(C.Structure):
+    _fields_ = [("u", C.c_float * 70), ("width", C.c_int32), ("height", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
+                ("accum_index", C.c_uint32), ("blend", C.c_int32), ("ndc_x", C.c_void_p), ("ndc_y", C.c_void_p),
+                ("rgba", C.c_void_p), ("depth", C.c_void_p), ("kind", C.c_void_p), ("slot", C.c_void_p), ("hit_t", C.c_void_p),
+                ("nrays", C.c_void_p), ("seed_out", C.c_void_p), ("debug", C.c_void_p), ("counters", C.c_uint64 * 8), ("threads", C.c_int32)]
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        build(targets=("librt_oracle.so",))
+        _LIB = C.CDLL(os.path.join(HERE, "librt_oracle.so"))
+        _LIB.oracle_render.argtypes = [C.POINTER(_Scene), C.POINTER(_Frame)]
+        _LIB.oracle_render.restype = C.c_int
+        _LIB.oracle_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        _LIB.oracle_sky.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_void_p, C.c_uint64]
+    return _LIB
+
+
+COUNTER_NAMES = ["rays", "node_pops", "triangle_tests", "child_box_tests", "child_pointer_words", "triangle_hits_shaded", "rays_entering_octree"]
+
+
+class OracleScene:
+    """Holds contiguous copies of the scene arrays (same contract as rt_scene_create)."""
+
+    def __init__(self, scene: dict, sky=None):
+        self.v = np.ascontiguousarray(scene["vertices"], np.float32).reshape(-1, 4)
+        self.n = np.ascontiguousarray(scene["normals"], np.float32).reshape(-1, 4)
+        self.t = np.ascontiguousarray(scene["tri_refs"], np.uint32).reshape(-1, 4)
+        self.k = np.ascontiguousarray(scene["nodes"], np.uint32).ravel()
+        self.sky = None if sky is None else np.ascontiguousarray(sky, np.uint8)
+        s = _Scene()
+        s.vertices, s.normals, s.tri_refs, s.nodes = self.v.ctypes.data, self.n.ctypes.data, self.t.ctypes.data, self.k.ctypes.data
+        s.n_vert, s.n_ref, s.n_words = len(self.v), len(self.t), len(self.k)
+        s.bounds_min[:] = [float(x) for x in np.asarray(scene["bounds_min"], np.float32)]
+        s.bounds_max[:] = [float(x) for x in np.asarray(scene["bounds_max"], np.float32)]
+        if self.sky is not None:
+            assert self.sky.ndim == 4 and self.sky.shape[0] == 6 and self.sky.shape[3] == 4
+            s.sky, s.sky_h, s.sky_w = self.sky.ctypes.data, self.sky.shape[1], self.sky.shape[2]
+        self.c = s
+
+    def render(self, uniforms70, width, height, *, accum_index=1, blend=True, rgba=None, rows=None, ndc=None, taps=True, threads=None, debug=False):
+        fr = _Frame()
+        u = np.ascontiguousarray(uniforms70, np.float32)
+        assert u.size == 70
+        C.memmove(fr.u, u.ctypes.data, 280)
+        fr.width, fr.height = width, height
+        fr.row_begin, fr.row_end = (0, height) if rows is None else rows
+        fr.accum_index, fr.blend = accum_index, int(blend)
+        out = {}
+        out["rgba"] = np.zeros((height, width, 4), np.float32) if rgba is None else np.ascontiguousarray(rgba, np.float32)
+        out["depth"] = np.zeros((height, width), np.float32)
+        fr.rgba, fr.depth = out["rgba"].ctypes.data, out["depth"].ctypes.data
+        if ndc is not None:
+            nx, ny = (np.ascontiguousarray(a, np.float32) for a in ndc)
+            assert nx.shape == (height, width) and ny.shape == (height, width)
+            fr.ndc_x, fr.ndc_y = nx.ctypes.data, ny.ctypes.data
+        if taps:
+            out["kind"] = np.zeros((height, width), np.uint32); fr.kind = out["kind"].ctypes.data
+            out["slot"] = np.zeros((height, width), np.uint32); fr.slot = out["slot"].ctypes.data
+            out["t"] = np.zeros((height, width), np.float32); fr.hit_t = out["t"].ctypes.data
+            out["nrays"] = np.zeros((height, width), np.uint32); fr.nrays = out["nrays"].ctypes.data
+            out["seed"] = np.zeros((height, width), np.float32); fr.seed_out = out["seed"].ctypes.data
+        if debug:
+            out["debug"] = np.zeros((height, width, 32), np.float32); fr.debug = out["debug"].ctypes.data
+        fr.threads = threads if threads is not None else min(16, os.cpu_count() or 1)
+        rc = _lib().oracle_render(C.byref(self.c), C.byref(fr))
+        if rc != 0:
+            raise RuntimeError(f"oracle_render failed rc={rc}")
+        out["counters"] = {n: int(fr.counters[i]) for i, n in enumerate(COUNTER_NAMES)}
+        return out
+
+    def sample_sky(self, dirs):
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        o = np.zeros_like(d)
+        _lib().oracle_sky(C.byref(self.c), d.ctypes.data, o.ctypes.data, len(d))
+        return o
+
+
+def math(op: str, x, y=None):
+    ops = {"sin": 0, "cos": 1, "log2": 2, "exp2": 3, "pow": 4}
+    x = np.ascontiguousarray(x, np.float32)
+    yy = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    o = np.zeros_like(x)
+    _lib().oracle_math(ops[op], x.ctypes.data, yy.ctypes.data, o.ctypes.data, x.size)
+    return o
