@@ -1,0 +1,168 @@
+/*
+ * rt_hotpath.h -- C ABI of the MI355X ray-tracing pass.
+ *
+ * Drop-in replacement for the render pass of monkeysoop/raytracer: everything the reference does between
+ * m_ray_tracer_shader.Use() and glDrawArrays in App::Render (app/core/src/App.cpp:107-140), the one-time
+ * buffer/cubemap uploads that feed it (App.cpp:23-26, Buffer.cpp:3-14, Skybox.cpp:46-57) and the
+ * fixed-function accumulate-blend into the RGBA32F target (App.cpp:49,97-105, Framebuffer.cpp:6-12).
+ * The work of the fragment shader app/assets/ray_tracer.frag runs as HIP kernels on gfx950.
+ *
+ * Conventions: plain pointers and sizes; every function returns RT_OK (0) or an RT_E* code and never throws;
+ * rt_last_error() gives the message of the calling thread's last failure.  A scene handle may be used by one
+ * thread at a time.  There is no CPU fallback: without a usable HIP device every call fails with RT_ENODEVICE.
+ */
+#ifndef RT_HOTPATH_H
+#define RT_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_EINVAL = 1,      /* bad argument (null pointer, zero size, unsupported value) */
+    RT_ESCENE = 2,      /* scene arrays are inconsistent (index / pointer out of range, tree too deep, ...) */
+    RT_ENODEVICE = 3,   /* no HIP device / HIP runtime error */
+    RT_ENOMEM = 4,
+    RT_ELIMIT = 5       /* size beyond a documented limit */
+};
+
+enum { RT_MEM_HOST = 0, RT_MEM_DEVICE = 1 };
+
+/* Primary-hit kinds written to rt_target.hit_kind. */
+enum { RT_HIT_MISS = 0, RT_HIT_SPHERE = 1, RT_HIT_TRIANGLE = 2, RT_HIT_CYLINDER = 3, RT_HIT_PORTAL_1 = 4, RT_HIT_PORTAL_2 = 5 };
+
+#define RT_NUM_MATERIALS 7u      /* ray_tracer.frag:95  */
+#define RT_MAX_TREE_DEPTH 40u    /* deepest octree the traversal stack is sized for (reference default depth limit: 18) */
+
+typedef struct rt_scene rt_scene;
+
+/* The uniforms of ray_tracer.frag:25-49 as App::Render sets them (App.cpp:120-138); mat4s are column-major as
+ * glm::value_ptr yields them.  `width`/`height` (frag:27-28) are unused by the shader and live in rt_frame.
+ * octree_min/max_bounds (frag:30-31) belong to the scene.  70 32-bit words. */
+typedef struct rt_uniforms {
+    float inv_view_proj_mat[16];   /* App.cpp:120 */
+    float camera_position[3];      /* App.cpp:121 */
+    uint32_t max_recursion_limit;  /* App.cpp:126 (reference: 5) */
+    float time;                    /* App.cpp:127 */
+    float blur_amount;             /* App.cpp:128 (reference: 1e-5) */
+    float portal_position_1[3];    /* App.cpp:129 */
+    float portal_direction_1[3];   /* App.cpp:130 */
+    float portal_position_2[3];    /* App.cpp:131 */
+    float portal_direction_2[3];   /* App.cpp:132 */
+    float portal_width;            /* App.cpp:133 */
+    float portal_height;           /* App.cpp:134 */
+    float portal_1_to_2[16];       /* App.cpp:135 */
+    float portal_2_to_1[16];       /* App.cpp:136 */
+    float z_near;                  /* App.cpp:137 */
+    float z_far;                   /* App.cpp:138 */
+} rt_uniforms;
+
+/* One draw of the fullscreen triangle (App.cpp:97-105,140). */
+typedef struct rt_frame {
+    rt_uniforms u;
+    uint32_t width, height;        /* target size in pixels; row 0 is the BOTTOM row (GL window coordinates) */
+    uint32_t accum_index;          /* n = m_still_frame_counter at App.cpp:104: dst = src*(1/n) + dst*(1 - 1/n); n >= 1 */
+    uint32_t blend;                /* 1: blend as above (GL_BLEND enabled, App.cpp:102); 0: store src (GL_BLEND disabled) */
+    /* Screen-space band selection for multi-GPU rendering: rows are cut into strips of `band_rows` rows and strip s
+     * is rendered iff s % band_parts == band_part.  band_parts = 1 renders every row. */
+    uint32_t band_rows, band_parts, band_part;
+    uint32_t reserved0;
+    /* Optional per-pixel NDC of the interpolated varying vs_out_ndc_coord (ray_tracer.vert:5-13), [height][width]
+     * floats each, in the memory space of rt_target.memory; NULL = closed form 2*(i+0.5)/size - 1. */
+    const float *ndc_x;
+    const float *ndc_y;
+    void *stream;                  /* hipStream_t to launch on (NULL = default stream) */
+} rt_frame;
+
+/* Render target: the colour attachment (RGBA32F, linear, Framebuffer.cpp:6) and optional extra planes.
+ * All planes are [height][width] (x4 for colour), always addressed by full-frame pixel index even when only a
+ * band is rendered; pixels outside the band are left untouched. */
+typedef struct rt_target {
+    int32_t memory;                /* RT_MEM_HOST or RT_MEM_DEVICE: where every pointer below (and ndc_x/ndc_y) lives */
+    int32_t sync;                  /* 1: return after the frame is complete; 0 (device memory only): return after enqueue */
+    float *color;                  /* required; read-modify-write when blend = 1 */
+    float *depth;                  /* optional: value the shader writes to gl_FragDepth (frag:671) */
+    uint32_t *hit_kind;            /* optional debug planes: primary hit kind (RT_HIT_*), */
+    uint32_t *hit_slot;            /*   sphere index or triangle-reference slot (index into tri_refs), */
+    float *hit_t;                  /*   hit distance, */
+    uint32_t *n_rays;              /*   FindIntersection calls (path segments) of the pixel */
+} rt_target;
+
+/* Work counters of the last rt_render on a scene (for roofline accounting). */
+typedef struct rt_stats {
+    uint64_t rays;                 /* path segments = FindIntersection calls (frag:573) */
+    uint64_t node_pops;            /* octree nodes visited (frag:455-461) */
+    uint64_t triangle_tests;       /* RayTriangle calls (frag:473) */
+    uint64_t child_box_tests;      /* child RayAABB calls (frag:504) */
+    uint64_t triangle_hits_shaded; /* segments whose closest hit is a triangle (frag:541-556) */
+    uint64_t rays_entering_octree; /* segments passing the root box test (frag:449) */
+} rt_stats;
+
+/* Library / device ------------------------------------------------------------------------------------------ */
+const char *rt_last_error(void);
+int rt_device_count(int *count);
+int rt_set_device(int device);     /* device used by subsequent rt_scene_create calls of this thread */
+
+/* Scene: the four SSBOs the reference uploads at App.cpp:23-26 (bindings 0-3, App.cpp:111-114) and the octree
+ * bounds (App.cpp:124-125).  Arrays are copied; the caller keeps ownership (glNamedBufferStorage(...,0) semantics,
+ * Buffer.cpp:5).  vertices/normals: [n_vert][4] floats (Octree::m_vertecies/m_normals, Octree.hpp:33-34);
+ * tri_refs: [n_ref][4] = (i0,i1,i2,material_id) (m_compressed_triangles, Octree.hpp:36); nodes: the flattened octree
+ * words (m_compressed_node_buffer, Octree.hpp:35; format written at Octree.cpp:44-75).  n_ref and n_words may be 0
+ * (no mesh).  The node buffer is validated and re-flattened into 64-byte node records for the device. */
+int rt_scene_create(const float *vertices, const float *normals, size_t n_vert,
+                    const uint32_t *tri_refs, size_t n_ref,
+                    const uint32_t *nodes, size_t n_words,
+                    const float bounds_min[3], const float bounds_max[3],
+                    rt_scene **out);
+/* Cubemap upload (Skybox.cpp:46-57): six RGBA8 faces in the order +x,-x,+y,-y,+z,-z, each [h][w][4] bytes with
+ * the first row being the first row of the uploaded surface; sampled LINEAR / CLAMP_TO_EDGE, non-seamless.
+ * Without a skybox texture() returns 0 like an unbound texture. */
+int rt_skybox_set(rt_scene *scene, const uint8_t *const faces[6], int w, int h);
+int rt_render(rt_scene *scene, const rt_frame *frame, const rt_target *target);
+int rt_scene_stats(rt_scene *scene, rt_stats *out);   /* counters of the last rt_render with sync = 1 or after a stream sync */
+/* Enables (1) / disables (0) work counters for subsequent renders of this scene (default off: counting costs time). */
+int rt_scene_set_counting(rt_scene *scene, int enabled);
+int rt_scene_destroy(rt_scene *scene);
+
+/* Host-side scene build: mirrors of the reference's Mesh and Octree classes --------------------------------- */
+
+/* Mesh::Mesh (Mesh.cpp:11-101) on an OBJ file with triangle faces: positions transformed by the column-major
+ * 4x4 `transform` with w = 0 (Mesh.cpp:44), normals from the file or accumulated face normals seeded with (1,0,0)
+ * (Mesh.cpp:52,79-83,96-99), triangles (i0,i1,i2,material_id).  Outputs are malloc'ed; free with rt_mesh_free. */
+typedef struct rt_mesh {
+    float *vertices;   /* [n_vert][4] */
+    float *normals;    /* [n_vert][4] */
+    uint32_t *triangles; /* [n_tri][4] */
+    size_t n_vert, n_tri;
+} rt_mesh;
+int rt_mesh_load_obj(const char *path, uint32_t material_id, const float transform[16], rt_mesh *out);
+/* Same from in-memory OBJ data: positions [n][3], optional file normals [n][3] (or NULL), faces [m][3] zero-based. */
+int rt_mesh_from_arrays(const float *positions, const float *file_normals, size_t n, const uint32_t *faces, size_t m,
+                        uint32_t material_id, const float transform[16], rt_mesh *out);
+void rt_mesh_free(rt_mesh *mesh);
+
+/* Octree::Octree (Octree.cpp:203-256): merges the meshes, computes the root box, subdivides
+ * (Octree.cpp:118-201, triangle/box test TriangleBoxIntersection.hpp:153-240) and flattens (Octree.cpp:38-85).
+ * Parameters as the reference constructor (Octree.hpp:27): depth_limit, max_triangles_per_node,
+ * max_triangles_per_leaf, keep_triangles_after_this_many_overlaps (reference scene: 18, 10, 6, 6, App.cpp:22). */
+typedef struct rt_octree {
+    float *vertices;       /* m_vertecies  [n_vert][4] */
+    float *normals;        /* m_normals    [n_vert][4] */
+    uint32_t *tri_refs;    /* m_compressed_triangles [n_ref][4] */
+    uint32_t *nodes;       /* m_compressed_node_buffer [n_words] */
+    size_t n_vert, n_ref, n_words;
+    float bounds_min[3], bounds_max[3];   /* GetMinBounds / GetMaxBounds */
+    size_t max_depth;
+} rt_octree;
+int rt_octree_build(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, size_t max_triangles_per_node,
+                    size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, rt_octree *out);
+void rt_octree_free(rt_octree *octree);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HOTPATH_H */

@@ -1,0 +1,259 @@
+/*
+ * TEST INFRASTRUCTURE -- CPU oracle for the scene build that feeds the ray-tracing pass.  Not
+ * shipped, not linked into the product.
+ *
+ * A plain recursive restatement of
+ *   /root/reference/app/core/src/Octree.cpp:118-256        (Subdivide, DepthFirstCompress, constructor)
+ *   /root/reference/app/core/include/TriangleBoxIntersection.hpp:8-240   (triangle/box SAT test)
+ *   /root/reference/app/core/src/Mesh.cpp:39-100            (vertex transform, normals, triangle records)
+ * with the arithmetic of the glm operations those files call (component-wise min/max as
+ * (b<a)?b:a / (a<b)?b:a, dot = (x+y)+z of the products, cross = (a.y*b.z - b.y*a.z, ...),
+ * normalize = v * (1/sqrt(dot)), mat4*vec4 = (c0*x + c1*y) + (c2*z + c3*w)).
+ *
+ * Parity status: the reference's own Octree.cpp cannot be built here without writing stand-ins for
+ * glm and GLEW headers that this image lacks, so this oracle is NOT pinned by a build of the
+ * reference ("parity unpinned").  What pins it instead: the array sizes the reference build printed
+ * for stanford_bunny.obj (529 434 triangle references, 654 908 node words, depth 17) recorded
+ * when the reference was surveyed, SHA-256 digests of that survey run's four output arrays
+ * (tests/golden/bunny_octree_digest.json), and the independent second implementation in the product
+ * (raytracer_amd/csrc/rt_octree_build.cpp) that must agree with this one bit-for-bit.
+ * OBJ text parsing in the reference goes through tinyobjloader 2.0.0-rc10 (not vendored, absent):
+ * the decimal->float conversion here is strtod + cast, unpinned; only triangle faces are accepted.
+ */
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct V3 { float x, y, z; float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); } };
+struct U4 { uint32_t x, y, z, w; };
+
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 half(V3 a) { return {a.x / 2.0f, a.y / 2.0f, a.z / 2.0f}; }
+inline float dot(V3 a, V3 b) { float px = a.x * b.x, py = a.y * b.y, pz = a.z * b.z; return (px + py) + pz; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline V3 vmin(V3 a, V3 b) { return {b.x < a.x ? b.x : a.x, b.y < a.y ? b.y : a.y, b.z < a.z ? b.z : a.z}; }
+inline V3 vmax(V3 a, V3 b) { return {a.x < b.x ? b.x : a.x, a.y < b.y ? b.y : a.y, a.z < b.z ? b.z : a.z}; }
+inline V3 normalize(V3 a) { float inv = 1.0f / std::sqrt(dot(a, a)); return {a.x * inv, a.y * inv, a.z * inv}; }
+
+struct Box { V3 lo, hi; };
+
+/* One edge-axis test of TriangleBoxIntersection.hpp:43-151: projections pa, pb of two vertices onto the
+ * axis against the box radius. */
+inline bool axis_separates(float pa, float pb, float rad) {
+    float mn, mx;
+    if (pa < pb) { mn = pa; mx = pb; } else { mn = pb; mx = pa; }
+    return mn > rad || mx < -rad;
+}
+
+/* TriangleBoxIntersection.hpp:20-39 */
+bool plane_box_overlap(V3 normal, V3 vert, V3 maxbox) {
+    float lo[3], hi[3];
+    for (int q = 0; q < 3; q++) {
+        float v = vert[q];
+        if (normal[q] > 0.0f) { lo[q] = -maxbox[q] - v; hi[q] = maxbox[q] - v; }
+        else { lo[q] = maxbox[q] - v; hi[q] = -maxbox[q] - v; }
+    }
+    if (dot(normal, V3{lo[0], lo[1], lo[2]}) > 0.0f) return false;
+    if (dot(normal, V3{hi[0], hi[1], hi[2]}) >= 0.0f) return true;
+    return false;
+}
+
+/* TriangleBoxIntersection.hpp:153-240 */
+bool tri_box_overlap(V3 c, V3 h, V3 t0, V3 t1, V3 t2) {
+    V3 v0 = t0 - c, v1 = t1 - c, v2 = t2 - c;
+    V3 e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
+    float fex, fey, fez;
+
+    fex = std::fabs(e0.x); fey = std::fabs(e0.y); fez = std::fabs(e0.z);
+    /* X01(e0.z, e0.y): p = a*v.y - b*v.z on v0, v2; rad = fa*h.y + fb*h.z */
+    if (axis_separates(e0.z * v0.y - e0.y * v0.z, e0.z * v2.y - e0.y * v2.z, fez * h.y + fey * h.z)) return false;
+    /* Y02(e0.z, e0.x): p = -a*v.x + b*v.z on v0, v2; rad = fa*h.x + fb*h.z */
+    if (axis_separates(-e0.z * v0.x + e0.x * v0.z, -e0.z * v2.x + e0.x * v2.z, fez * h.x + fex * h.z)) return false;
+    /* Z12(e0.y, e0.x): p = a*v.x - b*v.y on v1, v2; rad = fa*h.x + fb*h.y */
+    if (axis_separates(e0.y * v1.x - e0.x * v1.y, e0.y * v2.x - e0.x * v2.y, fey * h.x + fex * h.y)) return false;
+
+    fex = std::fabs(e1.x); fey = std::fabs(e1.y); fez = std::fabs(e1.z);
+    if (axis_separates(e1.z * v0.y - e1.y * v0.z, e1.z * v2.y - e1.y * v2.z, fez * h.y + fey * h.z)) return false;
+    if (axis_separates(-e1.z * v0.x + e1.x * v0.z, -e1.z * v2.x + e1.x * v2.z, fez * h.x + fex * h.z)) return false;
+    /* Z0(e1.y, e1.x) on v0, v1 */
+    if (axis_separates(e1.y * v0.x - e1.x * v0.y, e1.y * v1.x - e1.x * v1.y, fey * h.x + fex * h.y)) return false;
+
+    fex = std::fabs(e2.x); fey = std::fabs(e2.y); fez = std::fabs(e2.z);
+    /* X2(e2.z, e2.y) on v0, v1 */
+    if (axis_separates(e2.z * v0.y - e2.y * v0.z, e2.z * v1.y - e2.y * v1.z, fez * h.y + fey * h.z)) return false;
+    /* Y1(e2.z, e2.x) on v0, v1 */
+    if (axis_separates(-e2.z * v0.x + e2.x * v0.z, -e2.z * v1.x + e2.x * v1.z, fez * h.x + fex * h.z)) return false;
+    /* Z12(e2.y, e2.x) on v1, v2 */
+    if (axis_separates(e2.y * v1.x - e2.x * v1.y, e2.y * v2.x - e2.x * v2.y, fey * h.x + fex * h.y)) return false;
+
+    /* the three coordinate axes */
+    for (int q = 0; q < 3; q++) {
+        float a = v0[q], b = v1[q], d = v2[q], mn = a, mx = a;
+        if (b < mn) mn = b;
+        if (b > mx) mx = b;
+        if (d < mn) mn = d;
+        if (d > mx) mx = d;
+        if (mn > h[q] || mx < -h[q]) return false;
+    }
+    return plane_box_overlap(cross(e0, e1), v0, h);
+}
+
+/* Octree.cpp:18-23 */
+bool box_triangle_overlap(const Box &b, V3 a, V3 bb, V3 c) {
+    return tri_box_overlap(half(b.lo + b.hi), half(b.hi - b.lo), a, bb, c);
+}
+
+struct Node {
+    Box box;
+    std::vector<U4> tris;
+    std::array<std::unique_ptr<Node>, 8> kids;
+    bool leaf = true;
+};
+
+struct Builder {
+    const float *verts;   /* [n][4] */
+    size_t depth_limit, max_per_node, max_per_leaf, keep_after;
+    size_t max_depth = 0;
+    std::vector<uint32_t> nodes;
+    std::vector<U4> refs;
+
+    V3 vert(uint32_t i) const { return {verts[4 * (size_t)i], verts[4 * (size_t)i + 1], verts[4 * (size_t)i + 2]}; }
+
+    /* Octree.cpp:118-201 */
+    void subdivide(Node &n, size_t depth) {
+        if (depth >= depth_limit) return;
+        if (n.tris.size() <= max_per_leaf) { max_depth = std::max(max_depth, depth); return; }
+        max_depth = std::max(max_depth, depth);
+        n.leaf = false;
+        V3 mid = half(n.box.lo + n.box.hi);
+        for (int i = 0; i < 8; i++) {
+            n.kids[i] = std::make_unique<Node>();
+            n.kids[i]->box.lo = {(i & 1) ? mid.x : n.box.lo.x, (i & 2) ? mid.y : n.box.lo.y, (i & 4) ? mid.z : n.box.lo.z};
+            n.kids[i]->box.hi = {(i & 1) ? n.box.hi.x : mid.x, (i & 2) ? n.box.hi.y : mid.y, (i & 4) ? n.box.hi.z : mid.z};
+        }
+        struct Cand { std::vector<size_t> where; U4 tri; };
+        std::vector<Cand> cands;
+        for (const U4 &t : n.tris) {
+            V3 a = vert(t.x), b = vert(t.y), c = vert(t.z);
+            std::vector<size_t> where;
+            for (size_t k = 0; k < 8; k++) if (box_triangle_overlap(n.kids[k]->box, a, b, c)) where.push_back(k);
+            if (where.size() < keep_after) { for (size_t k : where) n.kids[k]->tris.push_back(t); }
+            else cands.push_back({where, t});
+        }
+        if (cands.size() > max_per_node) {
+            /* same library algorithm as the reference's call (heap select + heap sort of the head) */
+            std::partial_sort(cands.begin(), cands.begin() + (std::ptrdiff_t)max_per_node, cands.end(),
+                              [](const Cand &p, const Cand &q) { return p.where.size() > q.where.size(); });
+        }
+        std::vector<U4> kept;
+        for (size_t i = 0; i < std::min(cands.size(), max_per_node); i++) kept.push_back(cands[i].tri);
+        for (size_t i = max_per_node; i < cands.size(); i++) for (size_t k : cands[i].where) n.kids[k]->tris.push_back(cands[i].tri);
+        n.tris = std::move(kept);
+        for (int i = 0; i < 8; i++) if (!n.kids[i]->tris.empty()) subdivide(*n.kids[i], depth + 1);
+    }
+
+    /* Octree.cpp:38-85 */
+    void compress(const Node &n, size_t parent_slot) {
+        if (parent_slot != 0) nodes[parent_slot] = (uint32_t)nodes.size();
+        uint16_t count = (uint16_t)n.tris.size();
+        uint8_t mask = 0, kids = 0;
+        if (!n.leaf) for (int i = 0; i < 8; i++) if (!n.kids[i]->leaf || !n.kids[i]->tris.empty()) { mask |= (uint8_t)(1u << i); kids++; }
+        uint32_t info = ((uint32_t)count << 16) | ((uint32_t)mask << 8) | kids;   /* Octree.cpp:57 */
+        uint32_t start = (uint32_t)refs.size();
+        refs.insert(refs.end(), n.tris.begin(), n.tris.end());
+        nodes.push_back(info);
+        nodes.push_back(start);
+        size_t first = nodes.size();
+        for (int i = 0; i < kids; i++) nodes.push_back(0);
+        size_t k = 0;
+        for (int i = 0; i < 8; i++) if (mask & (1u << i)) { compress(*n.kids[i], first + k); k++; }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+struct octree_oracle_result {
+    uint32_t *nodes; uint64_t n_words;
+    uint32_t *tri_refs; uint64_t n_ref;     /* [n_ref][4] */
+    float bounds_min[3], bounds_max[3];
+    uint64_t max_depth;
+};
+
+/* vertices [n_vert][4] (already merged over meshes, Octree.cpp:221-233), triangles [n_tri][4] = (i0,i1,i2,material). */
+int octree_oracle_build(const float *vertices, uint64_t n_vert, const uint32_t *triangles, uint64_t n_tri,
+                        uint64_t depth_limit, uint64_t max_per_node, uint64_t max_per_leaf, uint64_t keep_after,
+                        octree_oracle_result *out) {
+    if (!vertices || !triangles || !out) return 1;
+    for (uint64_t i = 0; i < n_tri; i++) for (int k = 0; k < 3; k++) if (triangles[4 * i + k] >= n_vert) return 2;
+    Builder b; b.verts = vertices; b.depth_limit = depth_limit; b.max_per_node = max_per_node; b.max_per_leaf = max_per_leaf; b.keep_after = keep_after;
+    V3 lo{std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity()};
+    V3 hi{-lo.x, -lo.y, -lo.z};
+    Node root;
+    root.tris.reserve(n_tri);
+    for (uint64_t i = 0; i < n_tri; i++) {       /* Octree.cpp:234-246 */
+        U4 t{triangles[4 * i], triangles[4 * i + 1], triangles[4 * i + 2], triangles[4 * i + 3]};
+        root.tris.push_back(t);
+        for (uint32_t v : {t.x, t.y, t.z}) { lo = vmin(lo, b.vert(v)); hi = vmax(hi, b.vert(v)); }
+    }
+    root.box = {lo, hi};
+    b.subdivide(root, 1);          /* Octree.cpp:254 */
+    b.compress(root, 0);           /* Octree.cpp:255 */
+    out->n_words = b.nodes.size(); out->n_ref = b.refs.size();
+    out->nodes = (uint32_t *)malloc(sizeof(uint32_t) * std::max<size_t>(1, b.nodes.size()));
+    out->tri_refs = (uint32_t *)malloc(sizeof(uint32_t) * 4 * std::max<size_t>(1, b.refs.size()));
+    memcpy(out->nodes, b.nodes.data(), sizeof(uint32_t) * b.nodes.size());
+    memcpy(out->tri_refs, b.refs.data(), sizeof(uint32_t) * 4 * b.refs.size());
+    out->bounds_min[0] = lo.x; out->bounds_min[1] = lo.y; out->bounds_min[2] = lo.z;
+    out->bounds_max[0] = hi.x; out->bounds_max[1] = hi.y; out->bounds_max[2] = hi.z;
+    out->max_depth = b.max_depth;
+    return 0;
+}
+
+void octree_oracle_free(octree_oracle_result *r) { if (r) { free(r->nodes); free(r->tri_refs); r->nodes = nullptr; r->tri_refs = nullptr; } }
+
+/* Single triangle/box probe for unit tests. */
+int octree_oracle_tri_box(const float center[3], const float halfsize[3], const float tri[9]) {
+    return tri_box_overlap({center[0], center[1], center[2]}, {halfsize[0], halfsize[1], halfsize[2]},
+                           {tri[0], tri[1], tri[2]}, {tri[3], tri[4], tri[5]}, {tri[6], tri[7], tri[8]}) ? 1 : 0;
+}
+
+/* Mesh.cpp:39-100 on already-parsed OBJ data: positions [n][3], optional file normals [n][3], faces [m][3]
+ * (zero-based), material id, column-major 4x4 transform.  Writes vertices/normals [n][4], triangles [m][4]. */
+int mesh_oracle_build(const float *pos, const float *file_normals, uint64_t n, const uint32_t *faces, uint64_t m,
+                      uint32_t material_id, const float *T, float *vertices, float *normals, uint32_t *triangles) {
+    std::vector<V3> acc;
+    for (uint64_t i = 0; i < n; i++) {
+        float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2], w = 0.0f;   /* Mesh.cpp:44: w = 0 */
+        for (int r = 0; r < 4; r++) vertices[4 * i + r] = (T[0 + r] * x + T[4 + r] * y) + (T[8 + r] * z + T[12 + r] * w);
+        if (file_normals) { normals[4 * i] = file_normals[3 * i]; normals[4 * i + 1] = file_normals[3 * i + 1]; normals[4 * i + 2] = file_normals[3 * i + 2]; normals[4 * i + 3] = 0.0f; }
+        else acc.push_back({1.0f, 0.0f, 0.0f});                                    /* Mesh.cpp:52 */
+    }
+    for (uint64_t f = 0; f < m; f++) {
+        uint32_t a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+        if (a >= n || b >= n || c >= n) return 2;
+        if (!file_normals) {
+            V3 v1{vertices[4 * a], vertices[4 * a + 1], vertices[4 * a + 2]}, v2{vertices[4 * b], vertices[4 * b + 1], vertices[4 * b + 2]}, v3{vertices[4 * c], vertices[4 * c + 1], vertices[4 * c + 2]};
+            V3 nrm = normalize(cross(v2 - v1, v3 - v1));                           /* Mesh.cpp:79 */
+            acc[a] = acc[a] + nrm; acc[b] = acc[b] + nrm; acc[c] = acc[c] + nrm;
+        }
+        triangles[4 * f] = a; triangles[4 * f + 1] = b; triangles[4 * f + 2] = c; triangles[4 * f + 3] = material_id;
+    }
+    if (!file_normals) for (uint64_t i = 0; i < n; i++) { V3 q = normalize(acc[i]); normals[4 * i] = q.x; normals[4 * i + 1] = q.y; normals[4 * i + 2] = q.z; normals[4 * i + 3] = 0.0f; }
+    return 0;
+}
+
+}  // extern "C"

@@ -117,3 +117,77 @@ def math(op: str, x, y=None):
     o = np.zeros_like(x)
     _lib().oracle_math(ops[op], x.ctypes.data, yy.ctypes.data, o.ctypes.data, x.size)
     return o
+
+
+# ---------------------------------------------------------------------------------------------
+# Scene-build oracle (octree_oracle.cpp)
+# ---------------------------------------------------------------------------------------------
+class _OctResult(C.Structure):
+    _fields_ = [("nodes", C.POINTER(C.c_uint32)), ("n_words", C.c_uint64), ("tri_refs", C.POINTER(C.c_uint32)), ("n_ref", C.c_uint64),
+                ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("max_depth", C.c_uint64)]
+
+
+def _olib():
+    global _OLIB
+    if _OLIB is None:
+        build(targets=("liboctree_oracle.so",))
+        _OLIB = C.CDLL(os.path.join(HERE, "liboctree_oracle.so"))
+        _OLIB.octree_oracle_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(_OctResult)]
+        _OLIB.octree_oracle_build.restype = C.c_int
+        _OLIB.octree_oracle_free.argtypes = [C.POINTER(_OctResult)]
+        _OLIB.octree_oracle_tri_box.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _OLIB.octree_oracle_tri_box.restype = C.c_int
+        _OLIB.mesh_oracle_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _OLIB.mesh_oracle_build.restype = C.c_int
+    return _OLIB
+
+
+def parse_obj(path: str):
+    """Minimal OBJ reader for the oracle: 'v', optional 'vn', triangle 'f' records (a, a/b, a//c, a/b/c forms)."""
+    pos, nrm, faces = [], [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                pos.append([float(t) for t in line.split()[1:4]])
+            elif line.startswith("vn "):
+                nrm.append([float(t) for t in line.split()[1:4]])
+            elif line.startswith("f "):
+                idx = [int(t.split("/")[0]) for t in line.split()[1:]]
+                if len(idx) != 3:
+                    raise ValueError("only triangle faces are supported by the oracle reader")
+                faces.append([i - 1 if i > 0 else len(pos) + i for i in idx])
+    return (np.asarray(pos, np.float64).astype(np.float32), np.asarray(nrm, np.float64).astype(np.float32) if nrm else None,
+            np.asarray(faces, np.uint32))
+
+
+def mesh_build(pos, file_normals, faces, material_id: int, transform_cm):
+    """Mesh.cpp:39-100 -> (vertices[n,4], normals[n,4], triangles[m,4])."""
+    pos = np.ascontiguousarray(pos, np.float32); faces = np.ascontiguousarray(faces, np.uint32)
+    fn = None if file_normals is None else np.ascontiguousarray(file_normals, np.float32)
+    T = np.ascontiguousarray(transform_cm, np.float32).ravel()
+    n, m = len(pos), len(faces)
+    v = np.zeros((n, 4), np.float32); nn = np.zeros((n, 4), np.float32); t = np.zeros((m, 4), np.uint32)
+    rc = _olib().mesh_oracle_build(pos.ctypes.data, None if fn is None else fn.ctypes.data, n, faces.ctypes.data, m, material_id, T.ctypes.data,
+                                   v.ctypes.data, nn.ctypes.data, t.ctypes.data)
+    if rc:
+        raise RuntimeError(f"mesh_oracle_build rc={rc}")
+    return v, nn, t
+
+
+def octree_build(vertices, triangles, depth_limit=18, max_per_node=10, max_per_leaf=6, keep_after=6) -> dict:
+    """Octree.cpp:203-256 -> dict(nodes, tri_refs, bounds_min, bounds_max, max_depth).  Defaults: App.cpp:22."""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 4)
+    t = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 4)
+    r = _OctResult()
+    rc = _olib().octree_oracle_build(v.ctypes.data, len(v), t.ctypes.data, len(t), depth_limit, max_per_node, max_per_leaf, keep_after, C.byref(r))
+    if rc:
+        raise RuntimeError(f"octree_oracle_build rc={rc}")
+    out = dict(nodes=np.ctypeslib.as_array(r.nodes, (r.n_words,)).copy(), tri_refs=np.ctypeslib.as_array(r.tri_refs, (r.n_ref * 4,)).copy().reshape(-1, 4),
+               bounds_min=np.array(r.bounds_min[:], np.float32), bounds_max=np.array(r.bounds_max[:], np.float32), max_depth=int(r.max_depth))
+    _olib().octree_oracle_free(C.byref(r))
+    return out
+
+
+def tri_box(center, halfsize, tri) -> bool:
+    c = np.ascontiguousarray(center, np.float32); h = np.ascontiguousarray(halfsize, np.float32); t = np.ascontiguousarray(tri, np.float32).ravel()
+    return bool(_olib().octree_oracle_tri_box(c.ctypes.data, h.ctypes.data, t.ctypes.data))

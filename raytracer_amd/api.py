@@ -1,0 +1,302 @@
+"""ctypes binding of librt_hotpath.so (include/rt_hotpath.h) and a thin host-side mirror of the
+reference's scene interface.
+
+Names follow the reference where it has them: ``Mesh(filename, material_id, transform)`` with
+``m_vertecies / m_normals / m_triangles`` (/root/reference/app/core/include/Mesh.hpp:11-17) and
+``Octree(meshes, depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_after)`` with
+``m_vertecies / m_normals / m_compressed_node_buffer / m_compressed_triangles / GetMinBounds() /
+GetMaxBounds()`` (include/Octree.hpp:27-36).  ``RenderPass`` plays the part of App::Render's
+ray-tracing draw (src/App.cpp:96-140) including the progressive-accumulation counter
+(App.cpp:29,90-92,104-105).
+
+There is no fallback: if the shared library is missing or no HIP device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import Uniforms
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hotpath.so")
+
+RT_OK, RT_EINVAL, RT_ESCENE, RT_ENODEVICE, RT_ENOMEM, RT_ELIMIT = range(6)
+RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
+HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = range(6)
+
+EXPORTED_SYMBOLS = [
+    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_scene_stats",
+    "rt_scene_set_counting", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_free",
+]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rt_hotpath error {code}: {msg}")
+        self.code = code
+
+
+class rt_uniforms(C.Structure):
+    _fields_ = [("words", C.c_float * 70)]
+
+
+class rt_frame(C.Structure):
+    _fields_ = [("u", rt_uniforms), ("width", C.c_uint32), ("height", C.c_uint32), ("accum_index", C.c_uint32), ("blend", C.c_uint32),
+                ("band_rows", C.c_uint32), ("band_parts", C.c_uint32), ("band_part", C.c_uint32), ("reserved0", C.c_uint32),
+                ("ndc_x", C.c_void_p), ("ndc_y", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class rt_target(C.Structure):
+    _fields_ = [("memory", C.c_int32), ("sync", C.c_int32), ("color", C.c_void_p), ("depth", C.c_void_p), ("hit_kind", C.c_void_p),
+                ("hit_slot", C.c_void_p), ("hit_t", C.c_void_p), ("n_rays", C.c_void_p)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("node_pops", C.c_uint64), ("triangle_tests", C.c_uint64), ("child_box_tests", C.c_uint64),
+                ("triangle_hits_shaded", C.c_uint64), ("rays_entering_octree", C.c_uint64)]
+
+
+class rt_mesh(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("triangles", C.POINTER(C.c_uint32)),
+                ("n_vert", C.c_size_t), ("n_tri", C.c_size_t)]
+
+
+class rt_octree(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("tri_refs", C.POINTER(C.c_uint32)), ("nodes", C.POINTER(C.c_uint32)),
+                ("n_vert", C.c_size_t), ("n_ref", C.c_size_t), ("n_words", C.c_size_t), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
+                ("max_depth", C.c_size_t)]
+
+
+_lib = None
+
+
+def lib():
+    """Load librt_hotpath.so; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError(RT_ENODEVICE, f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.rt_set_device.argtypes = [C.c_int]
+        L.rt_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt_skybox_set.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        L.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_frame), C.POINTER(rt_target)]
+        L.rt_scene_stats.argtypes = [C.c_void_p, C.POINTER(rt_stats)]
+        L.rt_scene_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_destroy.argtypes = [C.c_void_p]
+        L.rt_mesh_load_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
+        L.rt_mesh_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
+        L.rt_mesh_free.argtypes = [C.POINTER(rt_mesh)]
+        L.rt_mesh_free.restype = None
+        L.rt_octree_build.argtypes = [C.POINTER(rt_mesh), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(rt_octree)]
+        L.rt_octree_free.argtypes = [C.POINTER(rt_octree)]
+        L.rt_octree_free.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().rt_device_count(C.byref(n))
+    return n.value if rc == RT_OK else 0
+
+
+IDENTITY = np.eye(4, dtype=np.float32)
+
+
+def scale_matrix(s: float) -> np.ndarray:
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0] = m[1, 1] = m[2, 2] = np.float32(s)
+    return m
+
+
+class Mesh:
+    """Mesh(filename, material_id, transform) -- Mesh.hpp:11-17.  `transform` is a [column][row] 4x4."""
+
+    def __init__(self, filename=None, material_id: int = 0, transform=IDENTITY, *, positions=None, normals=None, faces=None):
+        T = np.ascontiguousarray(transform, np.float32).reshape(16)
+        m = rt_mesh()
+        if filename is not None:
+            _check(lib().rt_mesh_load_obj(os.fsencode(filename), material_id, T.ctypes.data, C.byref(m)))
+        else:
+            p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+            f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
+            n = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+            _check(lib().rt_mesh_from_arrays(p.ctypes.data, None if n is None else n.ctypes.data, len(p), f.ctypes.data, len(f), material_id, T.ctypes.data, C.byref(m)))
+        try:
+            self.m_vertecies = np.ctypeslib.as_array(m.vertices, (m.n_vert, 4)).copy() if m.n_vert else np.zeros((0, 4), np.float32)
+            self.m_normals = np.ctypeslib.as_array(m.normals, (m.n_vert, 4)).copy() if m.n_vert else np.zeros((0, 4), np.float32)
+            self.m_triangles = np.ctypeslib.as_array(m.triangles, (m.n_tri, 4)).copy() if m.n_tri else np.zeros((0, 4), np.uint32)
+        finally:
+            lib().rt_mesh_free(C.byref(m))
+
+    @staticmethod
+    def from_buffers(vertices, normals, triangles) -> "Mesh":
+        """Wrap already-built [n,4] / [n,4] / [m,4] arrays."""
+        me = Mesh.__new__(Mesh)
+        me.m_vertecies = np.ascontiguousarray(vertices, np.float32).reshape(-1, 4)
+        me.m_normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 4)
+        me.m_triangles = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 4)
+        return me
+
+
+class Octree:
+    """Octree(meshes, depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_after) -- Octree.hpp:27-36."""
+
+    def __init__(self, meshes, depth_limit: int = 18, max_triangles_per_node: int = 10, max_triangles_per_leaf: int = 6,
+                 keep_triangles_after_this_many_overlaps: int = 6):
+        arr = (rt_mesh * max(1, len(meshes)))()
+        keep = []
+        for i, me in enumerate(meshes):
+            v, n, t = (np.ascontiguousarray(me.m_vertecies, np.float32), np.ascontiguousarray(me.m_normals, np.float32), np.ascontiguousarray(me.m_triangles, np.uint32))
+            keep += [v, n, t]
+            arr[i].vertices = v.ctypes.data_as(C.POINTER(C.c_float)); arr[i].normals = n.ctypes.data_as(C.POINTER(C.c_float))
+            arr[i].triangles = t.ctypes.data_as(C.POINTER(C.c_uint32)); arr[i].n_vert = len(v); arr[i].n_tri = len(t)
+        o = rt_octree()
+        _check(lib().rt_octree_build(arr, len(meshes), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, C.byref(o)))
+        try:
+            self.m_vertecies = np.ctypeslib.as_array(o.vertices, (o.n_vert, 4)).copy() if o.n_vert else np.zeros((0, 4), np.float32)
+            self.m_normals = np.ctypeslib.as_array(o.normals, (o.n_vert, 4)).copy() if o.n_vert else np.zeros((0, 4), np.float32)
+            self.m_compressed_triangles = np.ctypeslib.as_array(o.tri_refs, (o.n_ref, 4)).copy() if o.n_ref else np.zeros((0, 4), np.uint32)
+            self.m_compressed_node_buffer = np.ctypeslib.as_array(o.nodes, (o.n_words,)).copy() if o.n_words else np.zeros((0,), np.uint32)
+            self._min = np.array(o.bounds_min[:], np.float32)
+            self._max = np.array(o.bounds_max[:], np.float32)
+            self.max_depth = int(o.max_depth)
+        finally:
+            lib().rt_octree_free(C.byref(o))
+
+    def GetMinBounds(self) -> np.ndarray:
+        return self._min
+
+    def GetMaxBounds(self) -> np.ndarray:
+        return self._max
+
+    def as_dict(self) -> dict:
+        return dict(vertices=self.m_vertecies, normals=self.m_normals, tri_refs=self.m_compressed_triangles, nodes=self.m_compressed_node_buffer,
+                    bounds_min=self._min, bounds_max=self._max)
+
+
+class Scene:
+    """Device-resident scene: the four buffers of App.cpp:23-26 plus the octree bounds and the skybox."""
+
+    def __init__(self, vertices, normals, tri_refs, nodes, bounds_min, bounds_max, device: int | None = None):
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 4)
+        n = np.ascontiguousarray(normals, np.float32).reshape(-1, 4)
+        t = np.ascontiguousarray(tri_refs, np.uint32).reshape(-1, 4)
+        k = np.ascontiguousarray(nodes, np.uint32).ravel()
+        if len(n) != len(v):
+            raise RtError(RT_EINVAL, "vertices and normals differ in length")
+        lo = np.ascontiguousarray(bounds_min, np.float32); hi = np.ascontiguousarray(bounds_max, np.float32)
+        if device is not None:
+            _check(lib().rt_set_device(device))
+        h = C.c_void_p()
+        _check(lib().rt_scene_create(v.ctypes.data, n.ctypes.data, len(v), t.ctypes.data, len(t), k.ctypes.data, len(k), lo.ctypes.data, hi.ctypes.data, C.byref(h)))
+        self._h = h
+        self.n_ref, self.n_words = len(t), len(k)
+
+    @staticmethod
+    def from_octree(octree: Octree, device: int | None = None) -> "Scene":
+        return Scene(octree.m_vertecies, octree.m_normals, octree.m_compressed_triangles, octree.m_compressed_node_buffer,
+                     octree.GetMinBounds(), octree.GetMaxBounds(), device)
+
+    @staticmethod
+    def from_dict(d: dict, device: int | None = None) -> "Scene":
+        return Scene(d["vertices"], d["normals"], d["tri_refs"], d["nodes"], d["bounds_min"], d["bounds_max"], device)
+
+    def set_skybox(self, faces: np.ndarray):
+        """faces: uint8 [6, h, w, 4] in the order +x,-x,+y,-y,+z,-z (Skybox.cpp:11-18)."""
+        f = np.ascontiguousarray(faces, np.uint8)
+        if f.ndim != 4 or f.shape[0] != 6 or f.shape[3] != 4:
+            raise RtError(RT_EINVAL, "skybox must be uint8 [6, h, w, 4]")
+        ptrs = (C.c_void_p * 6)(*[f[i].ctypes.data for i in range(6)])
+        _check(lib().rt_skybox_set(self._h, ptrs, f.shape[2], f.shape[1]))
+
+    def set_counting(self, enabled: bool):
+        _check(lib().rt_scene_set_counting(self._h, int(enabled)))
+
+    def stats(self) -> dict:
+        s = rt_stats()
+        _check(lib().rt_scene_stats(self._h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in rt_stats._fields_}
+
+    def render_raw(self, frame: rt_frame, target: rt_target):
+        _check(lib().rt_render(self._h, C.byref(frame), C.byref(target)))
+
+    def render(self, uniforms, width: int, height: int, *, accum_index: int = 1, blend: bool = True, color: np.ndarray | None = None,
+               planes: bool = True, ndc=None, band=(16, 1, 0)) -> dict:
+        """Render one frame into host arrays (convenience path used by tests).  Returns dict(rgba, depth[, kind, slot, t, nrays])."""
+        u = uniforms.pack() if isinstance(uniforms, Uniforms) else np.ascontiguousarray(uniforms, np.float32)
+        fr = make_frame(u, width, height, accum_index=accum_index, blend=blend, band=band)
+        out = {"rgba": np.zeros((height, width, 4), np.float32) if color is None else np.ascontiguousarray(color, np.float32), "depth": np.zeros((height, width), np.float32)}
+        tg = rt_target()
+        tg.memory, tg.sync = RT_MEM_HOST, 1
+        tg.color, tg.depth = out["rgba"].ctypes.data, out["depth"].ctypes.data
+        if planes:
+            out["kind"] = np.zeros((height, width), np.uint32); tg.hit_kind = out["kind"].ctypes.data
+            out["slot"] = np.zeros((height, width), np.uint32); tg.hit_slot = out["slot"].ctypes.data
+            out["t"] = np.zeros((height, width), np.float32); tg.hit_t = out["t"].ctypes.data
+            out["nrays"] = np.zeros((height, width), np.uint32); tg.n_rays = out["nrays"].ctypes.data
+        if ndc is not None:
+            nx, ny = (np.ascontiguousarray(a, np.float32) for a in ndc)
+            assert nx.shape == (height, width) and ny.shape == (height, width)
+            fr.ndc_x, fr.ndc_y = nx.ctypes.data, ny.ctypes.data
+        self.render_raw(fr, tg)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_frame(uniforms70: np.ndarray, width: int, height: int, *, accum_index: int = 1, blend: bool = True, band=(16, 1, 0), stream: int | None = None) -> rt_frame:
+    u = np.ascontiguousarray(uniforms70, np.float32)
+    if u.size != 70:
+        raise RtError(RT_EINVAL, "uniform block must have 70 words")
+    fr = rt_frame()
+    C.memmove(C.byref(fr.u), u.ctypes.data, 280)
+    fr.width, fr.height, fr.accum_index, fr.blend = width, height, accum_index, int(blend)
+    fr.band_rows, fr.band_parts, fr.band_part = band
+    fr.stream = stream
+    return fr
+
+
+class RenderPass:
+    """The ray-tracing draw of App::Render with its progressive accumulation state, on device memory.
+
+    `color` is a device pointer to a [height][width][4] float32 target that persists across frames
+    (Framebuffer.cpp:6); `camera_changed()` resets the still-frame counter like App.cpp:90-92,209.
+    """
+
+    def __init__(self, scene: Scene, width: int, height: int, color_ptr: int, *, depth_ptr: int | None = None, band=(16, 1, 0), stream: int | None = None):
+        self.scene, self.width, self.height = scene, width, height
+        self.color_ptr, self.depth_ptr, self.band, self.stream = color_ptr, depth_ptr, band, stream
+        self.m_still_frame_counter = 1
+
+    def camera_changed(self):
+        self.m_still_frame_counter = 1
+
+    def Render(self, uniforms, sync: bool = False):
+        u = uniforms.pack() if isinstance(uniforms, Uniforms) else uniforms
+        fr = make_frame(u, self.width, self.height, accum_index=self.m_still_frame_counter, blend=True, band=self.band, stream=self.stream)
+        self.m_still_frame_counter += 1            # App.cpp:105
+        tg = rt_target()
+        tg.memory, tg.sync = RT_MEM_DEVICE, int(sync)
+        tg.color, tg.depth = self.color_ptr, self.depth_ptr
+        self.scene.render_raw(fr, tg)

@@ -1,0 +1,328 @@
+// Host side of the C ABI declared in include/rt_hotpath.h: scene validation and re-flattening, device memory,
+// the render entry point.  Replaces the GL resource handling around the reference's render pass
+// (app/core/src/App.cpp:23-26,96-140, Buffer.cpp:3-14, Skybox.cpp:46-57, Framebuffer.cpp:6-12).
+#include <hip/hip_runtime_api.h>
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_device = -1;   // -1: not chosen, use the current HIP device
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// The shader flushes denormals; the host-side precomputation of boxes and edges must do the same.
+struct FlushDenormals {
+    unsigned saved;
+    FlushDenormals() : saved(_mm_getcsr()) { _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON); }
+    ~FlushDenormals() { _mm_setcsr(saved); }
+};
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    RtDeviceScene d{};
+    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_sky = nullptr;
+    unsigned long long *d_counters = nullptr;
+    bool counting = false;
+    // staging for host-memory targets
+    void *s_color = nullptr, *s_depth = nullptr, *s_kind = nullptr, *s_slot = nullptr, *s_t = nullptr, *s_nrays = nullptr, *s_ndcx = nullptr, *s_ndcy = nullptr;
+    size_t s_pixels = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void free_staging(rt_scene *s) {
+    void **p[] = {&s->s_color, &s->s_depth, &s->s_kind, &s->s_slot, &s->s_t, &s->s_nrays, &s->s_ndcx, &s->s_ndcy};
+    for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    s->s_pixels = 0;
+}
+
+// Walks the reference node words (Octree.cpp:44-75; read by the shader at frag:460-464,481-484) from the root,
+// checks every offset the shader would dereference, and emits one 64-byte record per visited node in visit order.
+int flatten_nodes(const uint32_t *words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3],
+                  std::vector<RtNodeRec> &out, uint32_t &max_depth) {
+    out.clear();
+    max_depth = 0;
+    if (n_words == 0) return RT_OK;
+    if (n_words < 2) return fail(RT_ESCENE, "node buffer has %zu words; a node needs at least 2", n_words);
+    struct Item { uint32_t word, rec, depth; };
+    std::vector<Item> todo;
+    const size_t max_records = n_words;   // a tree cannot hold more nodes than words
+    auto add = [&](uint32_t word, const float lo[3], const float hi[3]) -> uint32_t {
+        RtNodeRec r{};
+        for (int k = 0; k < 8; k++) r.child[k] = RT_NO_CHILD;
+        for (int k = 0; k < 3; k++) { r.lo[k] = lo[k]; r.hi[k] = hi[k]; }
+        r.info = word;   // temporarily the word offset
+        out.push_back(r);
+        return (uint32_t)(out.size() - 1);
+    };
+    todo.push_back({0u, add(0u, lo0, hi0), 0u});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if ((size_t)it.word + 2 > n_words) return fail(RT_ESCENE, "node at word %u runs past the node buffer (%zu words)", it.word, n_words);
+        const uint32_t info = words[it.word], tri_start = words[it.word + 1];
+        const uint32_t child_count = info & 0xFu, mask = (info >> 8) & 0xFFu, tri_count = info >> 16;
+        if ((uint32_t)__builtin_popcount(mask) != child_count) return fail(RT_ESCENE, "node at word %u: child count %u does not match child mask 0x%02x", it.word, child_count, mask);
+        if ((info & 0xF0u) != 0) return fail(RT_ESCENE, "node at word %u: child count field has bits above 0xF set", it.word);
+        if ((size_t)it.word + 2 + child_count > n_words) return fail(RT_ESCENE, "node at word %u: child pointers run past the node buffer", it.word);
+        if ((size_t)tri_start + tri_count > n_ref) return fail(RT_ESCENE, "node at word %u: triangle range [%u,%u) exceeds %zu references", it.word, tri_start, tri_start + tri_count, n_ref);
+        if (it.depth > max_depth) max_depth = it.depth;
+        RtNodeRec &r = out[it.rec];
+        float lo[3], hi[3], mid[3];
+        for (int k = 0; k < 3; k++) { lo[k] = r.lo[k]; hi[k] = r.hi[k]; mid[k] = (hi[k] + lo[k]) / 2.0f; }   // frag:487
+        r.info = info;
+        r.tri_start = tri_start;
+        if (child_count && it.depth + 1 > RT_MAX_TREE_DEPTH) return fail(RT_ESCENE, "octree deeper than %u levels (or cyclic)", RT_MAX_TREE_DEPTH);
+        uint32_t ci = 0;
+        uint32_t child_rec[8];
+        for (int i = 0; i < 8; i++) {
+            if (!(mask & (1u << i))) continue;
+            const uint32_t cw = words[it.word + 2 + ci++];
+            float clo[3], chi[3];
+            for (int k = 0; k < 3; k++) {   // frag:491-500
+                const bool upper = (i >> k) & 1;
+                clo[k] = upper ? mid[k] : lo[k];
+                chi[k] = upper ? hi[k] : mid[k];
+            }
+            if (out.size() >= max_records) return fail(RT_ESCENE, "node buffer describes more than %zu nodes (shared or cyclic children)", max_records);
+            child_rec[i] = add(cw, clo, chi);
+            todo.push_back({cw, child_rec[i], it.depth + 1});
+        }
+        RtNodeRec &r2 = out[it.rec];   // `out` may have been reallocated by add()
+        for (int i = 0; i < 8; i++) if (mask & (1u << i)) r2.child[i] = child_rec[i];
+    }
+    return RT_OK;
+}
+
+int upload(void **dst, const void *src, size_t bytes) {
+    *dst = nullptr;
+    if (bytes == 0) return RT_OK;
+    HIP_TRY(hipMalloc(dst, bytes));
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+int rt_internal_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
+
+int rt_device_count(int *count) {
+    if (!count) return fail(RT_EINVAL, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(RT_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_set_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ENODEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return fail(RT_EINVAL, "device %d out of range [0,%d)", device, n);
+    g_device = device;
+    return RT_OK;
+}
+
+int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
+                    const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], rt_scene **out) {
+    if (!out) return fail(RT_EINVAL, "out is null");
+    *out = nullptr;
+    if (!bounds_min || !bounds_max) return fail(RT_EINVAL, "bounds are null");
+    if ((n_vert && (!vertices || !normals)) || (n_ref && !tri_refs) || (n_words && !nodes)) return fail(RT_EINVAL, "null array with non-zero size");
+    if (n_vert > 0xFFFFFFFFull || n_ref > 0xFFFFFFFFull || n_words > 0xFFFFFFFFull) return fail(RT_ELIMIT, "array sizes must fit 32 bits");
+    for (size_t i = 0; i < n_ref; i++) {
+        const uint32_t *t = tri_refs + 4 * i;
+        if (t[0] >= n_vert || t[1] >= n_vert || t[2] >= n_vert) return fail(RT_ESCENE, "triangle reference %zu indexes vertex >= %zu", i, n_vert);
+        if (t[3] >= RT_NUM_MATERIALS) return fail(RT_ESCENE, "triangle reference %zu has material id %u >= %u", i, t[3], RT_NUM_MATERIALS);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+    int dev = g_device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return fail(RT_ENODEVICE, "hipGetDevice failed"); }
+
+    std::vector<RtNodeRec> recs;
+    std::vector<RtTriRec> tris(n_ref);
+    uint32_t max_depth = 0;
+    {
+        FlushDenormals ftz;
+        int rc = flatten_nodes(nodes, n_words, n_ref, bounds_min, bounds_max, recs, max_depth);
+        if (rc != RT_OK) return rc;
+        for (size_t i = 0; i < n_ref; i++) {   // frag:469-471,256-257
+            const uint32_t *t = tri_refs + 4 * i;
+            const float *a = vertices + 4 * (size_t)t[0], *b = vertices + 4 * (size_t)t[1], *c = vertices + 4 * (size_t)t[2];
+            RtTriRec &r = tris[i];
+            r.v1[0] = a[0]; r.v1[1] = a[1]; r.v1[2] = a[2];
+            r.e1x = b[0] - a[0]; r.e1y = b[1] - a[1]; r.e1z = b[2] - a[2];
+            r.e2x = c[0] - a[0]; r.e2y = c[1] - a[1]; r.e2z = c[2] - a[2];
+            r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        }
+    }
+
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ENOMEM, "out of host memory");
+    s->device = dev;
+    DeviceGuard guard(dev);
+    if (!guard.ok) { delete s; return fail(RT_ENODEVICE, "cannot select HIP device %d", dev); }
+    int rc = RT_OK;
+    if ((rc = upload(&s->d_vertices, vertices, n_vert * 16)) || (rc = upload(&s->d_normals, normals, n_vert * 16)) ||
+        (rc = upload(&s->d_refs, tri_refs, n_ref * 16)) || (rc = upload(&s->d_nodes, recs.data(), recs.size() * sizeof(RtNodeRec))) ||
+        (rc = upload(&s->d_tris, tris.data(), tris.size() * sizeof(RtTriRec)))) {
+        rt_scene_destroy(s);
+        return rc;
+    }
+    if (hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_counters, 0, 64) != hipSuccess) {
+        rt_scene_destroy(s);
+        return fail(RT_ENOMEM, "cannot allocate counters");
+    }
+    s->d.vertices = (const float *)s->d_vertices; s->d.normals = (const float *)s->d_normals; s->d.tri_refs = (const uint32_t *)s->d_refs;
+    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.sky = nullptr;
+    s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = (uint32_t)recs.size();
+    s->d.sky_w = s->d.sky_h = 0;
+    for (int k = 0; k < 3; k++) { s->d.bounds_min[k] = bounds_min[k]; s->d.bounds_max[k] = bounds_max[k]; }
+    s->d.max_depth = max_depth;
+    *out = s;
+    return RT_OK;
+}
+
+int rt_skybox_set(rt_scene *s, const uint8_t *const faces[6], int w, int h) {
+    if (!s || !faces) return fail(RT_EINVAL, "null argument");
+    if (w <= 0 || h <= 0 || w > 16384 || h > 16384) return fail(RT_EINVAL, "skybox size %dx%d out of range", w, h);
+    for (int f = 0; f < 6; f++) if (!faces[f]) return fail(RT_EINVAL, "face %d is null", f);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
+    const size_t fb = (size_t)w * h * 4;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, fb * 6));
+    for (int f = 0; f < 6; f++) {
+        hipError_t e = hipMemcpy((char *)p + fb * f, faces[f], fb, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); return fail(RT_ENODEVICE, "skybox upload: %s", hipGetErrorString(e)); }
+    }
+    if (s->d_sky) (void)hipFree(s->d_sky);
+    s->d_sky = p;
+    s->d.sky = (const uint8_t *)p; s->d.sky_w = w; s->d.sky_h = h;
+    return RT_OK;
+}
+
+int rt_scene_set_counting(rt_scene *s, int enabled) {
+    if (!s) return fail(RT_EINVAL, "scene is null");
+    s->counting = enabled != 0;
+    return RT_OK;
+}
+
+int rt_scene_stats(rt_scene *s, rt_stats *out) {
+    if (!s || !out) return fail(RT_EINVAL, "null argument");
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
+    unsigned long long c[8];
+    HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    out->rays = c[0]; out->node_pops = c[1]; out->triangle_tests = c[2]; out->child_box_tests = c[3];
+    out->triangle_hits_shaded = c[4]; out->rays_entering_octree = c[5];
+    return RT_OK;
+}
+
+int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
+    if (!s || !f || !t) return fail(RT_EINVAL, "null argument");
+    if (!t->color) return fail(RT_EINVAL, "target colour plane is null");
+    if (f->width == 0 || f->height == 0 || f->width > 65536 || f->height > 65536) return fail(RT_EINVAL, "frame size %ux%u out of range", f->width, f->height);
+    if (f->accum_index == 0) return fail(RT_EINVAL, "accum_index must be >= 1");
+    if (f->band_parts == 0 || f->band_part >= f->band_parts || f->band_rows == 0) return fail(RT_EINVAL, "band selection %u/%u (rows %u) invalid", f->band_part, f->band_parts, f->band_rows);
+    if (t->memory != RT_MEM_HOST && t->memory != RT_MEM_DEVICE) return fail(RT_EINVAL, "target memory kind %d unknown", t->memory);
+    if ((f->ndc_x == nullptr) != (f->ndc_y == nullptr)) return fail(RT_EINVAL, "ndc_x and ndc_y must be given together");
+    if (t->memory == RT_MEM_HOST && !t->sync) return fail(RT_EINVAL, "host-memory targets require sync = 1");
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
+    hipStream_t st = (hipStream_t)f->stream;
+
+    // rows owned by this part: full strips plus the clipped last one
+    const uint32_t n_strips = (f->height + f->band_rows - 1) / f->band_rows;
+    const uint32_t my_strips = n_strips > f->band_part ? (n_strips - f->band_part + f->band_parts - 1) / f->band_parts : 0;
+    RtLaunch L{};
+    L.u = f->u;
+    L.width = f->width; L.height = f->height; L.accum_index = f->accum_index; L.blend = f->blend ? 1u : 0u;
+    L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
+    L.n_local_rows = my_strips * f->band_rows;
+    L.counters = s->counting ? s->d_counters : nullptr;
+    if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
+
+    const size_t px = (size_t)f->width * f->height;
+    const char *kerr = nullptr;
+    if (t->memory == RT_MEM_DEVICE) {
+        L.ndc_x = f->ndc_x; L.ndc_y = f->ndc_y;
+        L.color = t->color; L.depth = t->depth; L.hit_kind = t->hit_kind; L.hit_slot = t->hit_slot; L.hit_t = t->hit_t; L.n_rays = t->n_rays;
+        if (rt_launch_render(s->d, L, st, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
+        if (t->sync) HIP_TRY(hipStreamSynchronize(st));
+        return RT_OK;
+    }
+    // Host target: stage through device buffers owned by the scene.
+    if (s->s_pixels != px) {
+        free_staging(s);
+        HIP_TRY(hipMalloc(&s->s_color, px * 16)); HIP_TRY(hipMalloc(&s->s_depth, px * 4)); HIP_TRY(hipMalloc(&s->s_kind, px * 4));
+        HIP_TRY(hipMalloc(&s->s_slot, px * 4)); HIP_TRY(hipMalloc(&s->s_t, px * 4)); HIP_TRY(hipMalloc(&s->s_nrays, px * 4));
+        HIP_TRY(hipMalloc(&s->s_ndcx, px * 4)); HIP_TRY(hipMalloc(&s->s_ndcy, px * 4));
+        s->s_pixels = px;
+    }
+    HIP_TRY(hipMemcpyAsync(s->s_color, t->color, px * 16, hipMemcpyHostToDevice, st));   // read-modify-write target (blend) and untouched bands
+    if (f->ndc_x) {
+        HIP_TRY(hipMemcpyAsync(s->s_ndcx, f->ndc_x, px * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->s_ndcy, f->ndc_y, px * 4, hipMemcpyHostToDevice, st));
+        L.ndc_x = (const float *)s->s_ndcx; L.ndc_y = (const float *)s->s_ndcy;
+    }
+    struct Plane { void *host; void *dev; size_t bytes; };
+    Plane planes[] = {{t->depth, s->s_depth, px * 4}, {t->hit_kind, s->s_kind, px * 4}, {t->hit_slot, s->s_slot, px * 4}, {t->hit_t, s->s_t, px * 4}, {t->n_rays, s->s_nrays, px * 4}};
+    for (Plane &p : planes) if (p.host) HIP_TRY(hipMemcpyAsync(p.dev, p.host, p.bytes, hipMemcpyHostToDevice, st));
+    L.color = (float *)s->s_color;
+    L.depth = t->depth ? (float *)s->s_depth : nullptr; L.hit_kind = t->hit_kind ? (uint32_t *)s->s_kind : nullptr;
+    L.hit_slot = t->hit_slot ? (uint32_t *)s->s_slot : nullptr; L.hit_t = t->hit_t ? (float *)s->s_t : nullptr; L.n_rays = t->n_rays ? (uint32_t *)s->s_nrays : nullptr;
+    if (rt_launch_render(s->d, L, st, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
+    HIP_TRY(hipMemcpyAsync(t->color, s->s_color, px * 16, hipMemcpyDeviceToHost, st));
+    for (Plane &p : planes) if (p.host) HIP_TRY(hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene *s) {
+    if (!s) return RT_OK;
+    DeviceGuard guard(s->device);
+    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_sky, s->d_counters};
+    for (void *q : p) if (q) (void)hipFree(q);
+    free_staging(s);
+    delete s;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,650 @@
+// Device code of the ray-tracing pass for gfx950 (MI355X).
+//
+// What the reference's fragment shader app/assets/ray_tracer.frag does per pixel (cited as frag:N):
+// ray generation frag:674-687, closest hit over 84 analytic spheres / the triangle octree / one cylinder /
+// two portals frag:427-563, the path loop with Lambertian / metal / dielectric scattering frag:566-665,
+// environment lookup frag:662, filmic tonemap frag:667-668 and the accumulate-blend of
+// app/core/src/App.cpp:49,104.  Results must equal the reference's CPU execution (Mesa llvmpipe on x86):
+// IEEE binary32, flush-to-zero, NO contraction except inside the sin/cos/log2/exp2 polynomials (written as
+// explicit fmaf), dot products summed z,y,x.  Compile with -ffp-contract=off -fgpu-flush-denormals-to-zero.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rt_internal.h"
+
+#pragma clang fp contract(off)
+
+#define DEVI __device__ __forceinline__
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers (no fusing, fixed evaluation order)
+// ------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+DEVI f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEVI f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEVI f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEVI f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEVI f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+DEVI f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+DEVI float dot3(f3 a, f3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
+DEVI f3 cross3(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// IEEE-correct square root, divide and reciprocal: hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt)
+DEVI float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+DEVI float rcp_ieee(float x) { return 1.0f / x; }
+DEVI float div_ieee(float a, float b) { return a / b; }
+DEVI float length3(f3 a) { return sqrt_ieee(dot3(a, a)); }
+DEVI f3 normalize3(f3 a) { float inv = rcp_ieee(sqrt_ieee(dot3(a, a))); return a * inv; }
+DEVI f3 rcp3(f3 a) { return F3(rcp_ieee(a.x), rcp_ieee(a.y), rcp_ieee(a.z)); }
+DEVI uint32_t f2u(float f) { return __float_as_uint(f); }
+DEVI float u2f(uint32_t u) { return __uint_as_float(u); }
+DEVI bool is_inf(float x) { return __builtin_fabsf(x) == __builtin_inff(); }
+
+// ------------------------------------------------------------------------------------------------
+// transcendental functions exactly as the reference's CPU vehicle evaluates them
+// ------------------------------------------------------------------------------------------------
+template <bool IS_SIN> DEVI float sincos_poly(float x) {
+    const float xa = __builtin_fabsf(x);
+    int j = (int)(xa * 1.27323954473516f);   // 4/pi
+    j = (j + 1) & ~1;
+    const float yf = (float)j;
+    bool negate, sin_poly;
+    if (IS_SIN) { negate = ((j & 4) != 0) != (x < 0.0f); sin_poly = (j & 2) == 0; }
+    else { const int j3 = j - 2; negate = (~j3 & 4) != 0; sin_poly = (j3 & 2) == 0; }
+    float r = fmaf(yf, -0.78515625f, xa);
+    r = fmaf(yf, -2.4187564849853515625e-4f, r);
+    r = fmaf(yf, -3.77489497744594108e-8f, r);
+    const float z = r * r;
+    float s = fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    s = fmaf(s, z, -1.6666654611E-1f);
+    s = s * z;
+    s = fmaf(s, r, r);
+    float c = fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    c = fmaf(c, z, 4.166664568298827E-002f);
+    c = c * z;
+    c = c * z;
+    c = c - z * 0.5f;
+    c = c + 1.0f;
+    const float out = sin_poly ? s : c;
+    return negate ? -out : out;
+}
+DEVI float log2_poly(float v) {
+    if (v == 0.0f) return -__builtin_inff();
+    const int i = (int)f2u(v);
+    const float ex = (float)(((i >> 23) & 0xff) - 127);
+    const float m = u2f(((uint32_t)i & 0x007fffffu) | 0x3f800000u);
+    const float y = div_ieee(m - 1.0f, m + 1.0f);
+    const float z = y * y, z2 = z * z;
+    const float even = fmaf(z2, fmaf(z2, (float)0.40671805249884624, (float)0.5774403394387364), (float)2.8853900934330916);
+    const float odd = fmaf(z2, (float)0.4033438582513299, (float)0.9617915504041842);
+    return fmaf(y, fmaf(odd, z, even), ex);
+}
+DEVI float exp2_poly(float v) {
+    v = fminf(fmaxf(v, -126.99999f), 129.0f);
+    const float ip = __builtin_floorf(v), fp = v - ip;
+    const float scale = u2f((uint32_t)(((int)ip + 127) << 23));
+    const float f2 = fp * fp;
+    const float even = fmaf(f2, fmaf(f2, (float)0.008989340090494664, (float)0.24015361704437538), 1.0f);
+    const float odd = fmaf(f2, fmaf(f2, (float)0.001877576675191479, (float)0.055826318053295666), (float)0.693153073200169);
+    return scale * fmaf(odd, fp, even);
+}
+DEVI float pow_poly(float x, float y) { return exp2_poly(log2_poly(x) * y); }
+
+// frag:359-363
+DEVI uint32_t base_hash(uint32_t px, uint32_t py) {
+    const uint32_t qx = 1103515245u * ((px >> 1) ^ py);
+    const uint32_t qy = 1103515245u * ((py >> 1) ^ px);
+    const uint32_t h = 1103515245u * (qx ^ (qy >> 3));
+    return h ^ (h >> 16);
+}
+
+// The shader compiler folds chains of `seed += .1` inside one iteration of the path loop into base + c_k with
+// c_k = fl(c_{k-1} + 0.1f); the base re-materialises once per iteration.
+struct Seed {
+    float base; int k;
+    DEVI float c(int i) const {
+        const float c1 = 0.1f, c2 = c1 + 0.1f, c3 = c2 + 0.1f, c4 = c3 + 0.1f;
+        return i == 0 ? 0.0f : (i == 1 ? c1 : (i == 2 ? c2 : (i == 3 ? c3 : c4)));
+    }
+    DEVI uint32_t next_hash() {   // baseHash(floatBitsToUint(vec2(seed+=.1, seed+=.1)))  frag:367,373,380
+        const float a = base + c(k + 1), b = base + c(k + 2);
+        k += 2;
+        return base_hash(f2u(a), f2u(b));
+    }
+    DEVI void rebase() { base = base + c(k); k = 0; }
+};
+DEVI float hash1(Seed &s) { return (float)s.next_hash() / 4294967296.0f; }   // frag:366-369 (power-of-two divisor: exact)
+
+// frag:399-404
+DEVI f3 random_in_unit_sphere(Seed &s) {
+    const uint32_t n = s.next_hash();
+    const float h3x = (float)(n & 0x7fffffffu) / 2147483648.0f;
+    const float h3y = (float)((n * 16807u) & 0x7fffffffu) / 2147483648.0f;
+    const float h3z = (float)((n * 48271u) & 0x7fffffffu) / 2147483648.0f;
+    const float hx = h3x * 2.0f - 1.0f;
+    const float phi = h3y * 6.28318530718f;
+    const float r = pow_poly(h3z, 1.0f / 3.0f);
+    const float q = sqrt_ieee(1.0f - hx * hx);
+    return F3(r * (q * sincos_poly<true>(phi)), r * (q * sincos_poly<false>(phi)), r * hx);
+}
+// frag:386-396
+DEVI f3 random_cos_weighted_hemisphere_direction(f3 n, Seed &s) {
+    const uint32_t h = s.next_hash();
+    const float r_x = (float)(h & 0x7fffffffu) / 2147483648.0f;
+    const float r_y = (float)((h * 48271u) & 0x7fffffffu) / 2147483648.0f;
+    const f3 axis = __builtin_fabsf(n.y) > 0.5f ? F3(1.0f, 0.0f, 0.0f) : F3(0.0f, 1.0f, 0.0f);
+    const f3 uu = normalize3(cross3(n, axis));
+    const f3 vv = cross3(uu, n);
+    const float ra = sqrt_ieee(r_y);
+    const float rx = ra * sincos_poly<false>(6.28318530718f * r_x);
+    const float ry = ra * sincos_poly<true>(6.28318530718f * r_x);
+    const float rz = sqrt_ieee(1.0f - r_y);
+    return normalize3((uu * rx + vv * ry) + n * rz);
+}
+DEVI f3 reflect3(f3 I, f3 N) { const float d = dot3(N, I); return I - N * (2.0f * d); }
+DEVI f3 refract3(f3 I, f3 N, float eta) {
+    const float ndi = dot3(N, I);
+    const float k = 1.0f - eta * (eta * (1.0f - ndi * ndi));
+    if (k < 0.0f) return F3(0.0f, 0.0f, 0.0f);
+    return I * eta - N * (eta * ndi + sqrt_ieee(k));
+}
+// frag:412-414
+DEVI float fresnel_schlick_roughness(float cos_theta, float F0, float roughness) {
+    return F0 + (fmaxf(1.0f - roughness, F0) - F0) * pow_poly(__builtin_fabsf(1.0f - cos_theta), 5.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene constants of the shader (frag:95-201)
+// ------------------------------------------------------------------------------------------------
+struct Material { uint32_t type; float r, g, b, roughness, refractive_index; };
+enum { LAMBERTIAN = 0, METAL = 1, DIELECTRIC = 2 };
+__constant__ Material c_materials[7] = {
+    {METAL, 0.3f, 0.5f, 0.4f, 0.1f, 1.5f},   {METAL, 1.0f, 0.71f, 0.29f, 0.02f, 1.5f}, {LAMBERTIAN, 0.0f, 1.0f, 0.0f, 0.3f, 1.5f},
+    {METAL, 1.0f, 1.0f, 0.0f, 0.9f, 1.5f},   {METAL, 1.0f, 0.0f, 0.0f, 0.01f, 1.5f},  {DIELECTRIC, 0.0f, 1.0f, 1.0f, 0.3f, 1.8f},
+    {DIELECTRIC, 0.0f, 1.0f, 1.0f, 0.0f, 1.5f},
+};
+#define NUM_SPHERES 84
+// centre xyz + radius; sphere 0 is the ground, 1..80 the small ones (y = r = 0.2), 81..83 the big ones
+__constant__ float4 c_spheres[NUM_SPHERES] = {
+    {0.0f, -1003.0f, 0.0f, 1000.0f},
+    {-7.995381f, 0.2f, -7.478668f, 0.2f}, {-7.696819f, 0.2f, -5.468978f, 0.2f}, {-7.824804f, 0.2f, -3.120637f, 0.2f}, {-7.132909f, 0.2f, -1.701323f, 0.2f},
+    {-7.569523f, 0.2f, 0.494554f, 0.2f},  {-7.730332f, 0.2f, 2.358976f, 0.2f},  {-7.892865f, 0.2f, 4.753728f, 0.2f},  {-7.656691f, 0.2f, 6.888913f, 0.2f},
+    {-7.217835f, 0.2f, 8.203466f, 0.2f},  {-5.115232f, 0.2f, -7.980404f, 0.2f}, {-5.323222f, 0.2f, -5.113037f, 0.2f}, {-5.410681f, 0.2f, -3.527741f, 0.2f},
+    {-5.460670f, 0.2f, -1.166543f, 0.2f}, {-5.457659f, 0.2f, 0.363870f, 0.2f},  {-5.798715f, 0.2f, 2.161684f, 0.2f},  {-5.116586f, 0.2f, 4.470188f, 0.2f},
+    {-5.273591f, 0.2f, 6.795187f, 0.2f},  {-5.120286f, 0.2f, 8.731398f, 0.2f},  {-3.601565f, 0.2f, -7.895600f, 0.2f}, {-3.735860f, 0.2f, -5.163056f, 0.2f},
+    {-3.481116f, 0.2f, -3.794556f, 0.2f}, {-3.866858f, 0.2f, -1.465965f, 0.2f}, {-3.168870f, 0.2f, 0.553099f, 0.2f},  {-3.428552f, 0.2f, 2.627547f, 0.2f},
+    {-3.771736f, 0.2f, 4.324785f, 0.2f},  {-3.768522f, 0.2f, 6.384588f, 0.2f},  {-3.286992f, 0.2f, 8.441148f, 0.2f},  {-1.552127f, 0.2f, -7.728200f, 0.2f},
+    {-1.360796f, 0.2f, -5.346098f, 0.2f}, {-1.287209f, 0.2f, -3.735321f, 0.2f}, {-1.344859f, 0.2f, -1.726654f, 0.2f}, {-1.974774f, 0.2f, 0.183260f, 0.2f},
+    {-1.542872f, 0.2f, 2.067868f, 0.2f},  {-1.743856f, 0.2f, 4.752810f, 0.2f},  {-1.955621f, 0.2f, 6.493702f, 0.2f},  {-1.350449f, 0.2f, 8.068503f, 0.2f},
+    {0.706123f, 0.2f, -7.116040f, 0.2f},  {0.897766f, 0.2f, -5.938681f, 0.2f},  {0.744113f, 0.2f, -3.402960f, 0.2f},  {0.867750f, 0.2f, -1.311908f, 0.2f},
+    {0.082480f, 0.2f, 0.838206f, 0.2f},   {0.649692f, 0.2f, 2.525103f, 0.2f},   {0.378574f, 0.2f, 4.055579f, 0.2f},   {0.425844f, 0.2f, 6.098526f, 0.2f},
+    {0.261365f, 0.2f, 8.661150f, 0.2f},   {2.814218f, 0.2f, -7.751227f, 0.2f},  {2.050073f, 0.2f, -5.731364f, 0.2f},  {2.020130f, 0.2f, -3.472627f, 0.2f},
+    {2.884277f, 0.2f, -1.232662f, 0.2f},  {2.644454f, 0.2f, 0.596324f, 0.2f},   {2.194283f, 0.2f, 2.880603f, 0.2f},   {2.281000f, 0.2f, 4.094307f, 0.2f},
+    {2.080841f, 0.2f, 6.716384f, 0.2f},   {2.287131f, 0.2f, 8.583242f, 0.2f},   {4.329136f, 0.2f, -7.497218f, 0.2f},  {4.502115f, 0.2f, -5.941060f, 0.2f},
+    {4.750631f, 0.2f, -3.836759f, 0.2f},  {4.082084f, 0.2f, -1.180746f, 0.2f},  {4.429173f, 0.2f, 2.069721f, 0.2f},   {4.277152f, 0.2f, 4.297482f, 0.2f},
+    {4.012743f, 0.2f, 6.225072f, 0.2f},   {4.047066f, 0.2f, 8.419360f, 0.2f},   {6.441846f, 0.2f, -7.700798f, 0.2f},  {6.047810f, 0.2f, -5.519369f, 0.2f},
+    {6.779211f, 0.2f, -3.740542f, 0.2f},  {6.430776f, 0.2f, -1.332107f, 0.2f},  {6.476387f, 0.2f, 0.329973f, 0.2f},   {6.568686f, 0.2f, 2.116949f, 0.2f},
+    {6.371189f, 0.2f, 4.609841f, 0.2f},   {6.011877f, 0.2f, 6.569579f, 0.2f},   {6.096087f, 0.2f, 8.892333f, 0.2f},   {8.185763f, 0.2f, -7.191109f, 0.2f},
+    {8.411960f, 0.2f, -5.285309f, 0.2f},  {8.047109f, 0.2f, -3.427552f, 0.2f},  {8.119639f, 0.2f, -1.652587f, 0.2f},  {8.818120f, 0.2f, 0.401292f, 0.2f},
+    {8.754155f, 0.2f, 2.152549f, 0.2f},   {8.595298f, 0.2f, 4.802001f, 0.2f},   {8.036216f, 0.2f, 6.739752f, 0.2f},   {8.256561f, 0.2f, 8.129115f, 0.2f},
+    {0.0f, 2.0f, 0.0f, 1.0f}, {-4.0f, 2.0f, 0.0f, 1.0f}, {4.0f, 2.0f, 0.0f, 1.0f},
+};
+
+// ------------------------------------------------------------------------------------------------
+// intersection
+// ------------------------------------------------------------------------------------------------
+struct Ray { f3 pos, dir, inv; };
+struct Hit { bool has_hit; f3 position, normal; uint32_t material_id, portal_id; };
+struct PrimaryTap { uint32_t kind, slot; float t; };
+struct Counters { uint32_t rays, pops, tri_tests, box_tests, tri_shaded, entered; };
+
+// frag:417-425
+DEVI bool ray_aabb(const Ray &r, f3 lo, f3 hi, float closest) {
+    const f3 t1 = (lo - r.pos) * r.inv, t2 = (hi - r.pos) * r.inv;
+    const float tmin = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z));
+    const float tmax = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
+    return tmax > 0.0f && tmin < tmax && tmin < closest;
+}
+
+// frag:233-252 over frag:439-445.  Each sphere's candidate t does not depend on the running closest distance
+// except through the final filter, so the loop keeps the reference's sequential accept rule unchanged.
+DEVI void intersect_spheres(const Ray &r, float &closest, uint32_t &closest_i) {
+#pragma unroll 4
+    for (uint32_t i = 0; i < NUM_SPHERES; i++) {
+        const float4 s = c_spheres[i];
+        const f3 oc = r.pos - F3(s.x, s.y, s.z);
+        const float b = dot3(oc, r.dir);
+        const float c = dot3(oc, oc) - s.w * s.w;
+        const float disc = b * b - c;
+        if (disc < 0.0f) continue;
+        const float sq = sqrt_ieee(disc);
+        const float t1 = -b - sq, t2 = -b + sq;
+        const float t = t1 < 0.0f ? t2 : t1;
+        if (t < closest && t > 0.0f) { closest = t; closest_i = i; }
+    }
+}
+
+// frag:255-281 on a prepared triangle record
+DEVI float ray_triangle(const Ray &r, const RtTriRec *tr) {
+    const float4 q0 = *reinterpret_cast<const float4 *>(tr);
+    const float4 q1 = *(reinterpret_cast<const float4 *>(tr) + 1);
+    const float q2 = tr->e2z;
+    const f3 v1 = F3(q0.x, q0.y, q0.z), e1 = F3(q0.w, q1.x, q1.y), e2 = F3(q1.z, q1.w, q2);
+    const f3 pvec = cross3(r.dir, e2);
+    const float det = dot3(e1, pvec);
+    if (__builtin_fabsf(det) < 0.000000000000001f) return -1.0f;
+    const float inv_det = rcp_ieee(det);
+    const f3 tvec = r.pos - v1;
+    const float u = inv_det * dot3(tvec, pvec);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const f3 qvec = cross3(tvec, e1);
+    const float v = inv_det * dot3(r.dir, qvec);
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    return dot3(e2, qvec) * inv_det;
+}
+
+// frag:455-514: depth-first, children pushed in ascending octant order and popped from the top, pruned at push
+// time against the closest distance known then -- the visit order decides which duplicate of a triangle wins
+// ties, so it is kept exactly.
+template <int STACK, bool COUNT>
+DEVI void traverse_octree(const RtDeviceScene &S, const Ray &r, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
+    if (S.n_nodes == 0) return;
+    if (!ray_aabb(r, F3(S.bounds_min[0], S.bounds_min[1], S.bounds_min[2]), F3(S.bounds_max[0], S.bounds_max[1], S.bounds_max[2]), closest)) return;
+    if (COUNT) cn.entered++;
+    uint32_t stack[STACK];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp != 0) {
+        const uint32_t ni = stack[--sp];
+        const uint4 *rec = reinterpret_cast<const uint4 *>(S.nodes + ni);
+        const uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
+        const uint32_t info = w0.x, tri_start = w0.y;
+        const uint32_t tri_count = info >> 16;
+        if (COUNT) { cn.pops++; cn.tri_tests += tri_count; }
+        for (uint32_t i = 0; i < tri_count; i++) {
+            const float t = ray_triangle(r, S.tris + (tri_start + i));
+            if (t >= 0.0f && t < closest) { closest = t; closest_tri = tri_start + i; tri_hit = true; }
+        }
+        const uint32_t mask = (info >> 8) & 0xffu;
+        if (mask == 0) continue;
+        const uint32_t child[8] = {w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y};
+        const f3 lo = F3(u2f(w2.z), u2f(w2.w), u2f(w3.x)), hi = F3(u2f(w3.y), u2f(w3.z), u2f(w3.w));
+        const f3 mid = F3((hi.x + lo.x) / 2.0f, (hi.y + lo.y) / 2.0f, (hi.z + lo.z) / 2.0f);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (mask & (1u << i)) {
+                const f3 clo = F3((i & 1) ? mid.x : lo.x, (i & 2) ? mid.y : lo.y, (i & 4) ? mid.z : lo.z);
+                const f3 chi = F3((i & 1) ? hi.x : mid.x, (i & 2) ? hi.y : mid.y, (i & 4) ? hi.z : mid.z);
+                if (COUNT) cn.box_tests++;
+                if (ray_aabb(r, clo, chi, closest) && sp < STACK) stack[sp++] = child[i];
+            }
+        }
+    }
+}
+
+DEVI float sign1(float y) { return y > 0.0f ? 1.0f : (y < 0.0f ? -1.0f : 0.0f); }
+
+// frag:284-318 with the constant arguments of frag:518; the compiler the reference runs under pulls the folded
+// constant ra*ra*caca inward: c = (caca*dot(oc,oc) - K) - caoc*caoc.
+DEVI float ray_cylinder(const Ray &r, float closest, f3 &normal) {
+    const f3 pa = F3(2.1f, 0.1f, -2.0f), pb = F3(1.9f, 0.5f, -1.9f);
+    const float ra = 0.08f;
+    const f3 ca = pb - pa;
+    const f3 oc = r.pos - pa;
+    const float caca = dot3(ca, ca);
+    const float card = dot3(ca, r.dir);
+    const float caoc = dot3(ca, oc);
+    const float a = caca - card * card;
+    const float b = caca * dot3(oc, r.dir) - caoc * card;
+    const float c = (caca * dot3(oc, oc) - ra * ra * caca) - caoc * caoc;
+    float h = b * b - a * c;
+    if (h < 0.0f) return __builtin_inff();
+    h = sqrt_ieee(h);
+    float d = div_ieee(-b - h, a);
+    const float y = caoc + d * card;
+    if (y > 0.0f && y < caca && d >= 0.0f && d <= closest) {
+        const f3 p = (oc + r.dir * d) - F3(div_ieee(ca.x * y, caca), div_ieee(ca.y * y, caca), div_ieee(ca.z * y, caca));
+        normal = F3(div_ieee(p.x, ra), div_ieee(p.y, ra), div_ieee(p.z, ra));
+        return d;
+    }
+    d = div_ieee((y < 0.0f ? 0.0f : caca) - caoc, card);
+    if (__builtin_fabsf(b + a * d) < h && d >= 0.0f && d <= closest) {
+        const float sy = sign1(y);
+        normal = normalize3(F3(div_ieee(ca.x * sy, caca), div_ieee(ca.y * sy, caca), div_ieee(ca.z * sy, caca)));
+        return d;
+    }
+    return __builtin_inff();
+}
+
+// frag:320-350
+DEVI float ray_portal(const Ray &r, f3 ppos, f3 pn, float pw, float ph, float closest) {
+    const float d = dot3(pn, r.dir);
+    if (__builtin_fabsf(d) <= 0.0001f) return __builtin_inff();
+    const float t = div_ieee(dot3(ppos - r.pos, pn), d);
+    if (t < 0.0f || t > closest) return __builtin_inff();
+    const f3 ip = r.pos + r.dir * t;
+    f3 right = cross3(pn, F3(0.0f, 1.0f, 0.0f));
+    if (length3(right) <= 0.0001f) return __builtin_inff();
+    right = normalize3(right);
+    const f3 up = normalize3(cross3(right, pn));
+    const f3 c = ip - ppos;
+    if (__builtin_fabsf(dot3(right, c)) < 0.5f * pw && __builtin_fabsf(dot3(up, c)) < 0.5f * ph) return t;
+    return __builtin_inff();
+}
+
+DEVI f3 load_xyz(const float *base, uint32_t i) {
+    const float4 v = *reinterpret_cast<const float4 *>(base + 4 * (size_t)i);
+    return F3(v.x, v.y, v.z);
+}
+
+// frag:215-230
+DEVI f3 barycentric(f3 p, f3 a, f3 b, f3 c) {
+    const f3 v0 = b - a, v1 = c - a, v2 = p - a;
+    const float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+    const float denom = d00 * d11 - d01 * d01;
+    const float v = div_ieee(d11 * d20 - d01 * d21, denom);
+    const float w = div_ieee(d00 * d21 - d01 * d20, denom);
+    const float u = 1.0f - v - w;
+    return F3(u, v, w);
+}
+
+// frag:427-563
+template <int STACK, bool COUNT>
+DEVI Hit find_intersection(const RtDeviceScene &S, const rt_uniforms &U, const Ray &r, PrimaryTap *tap, Counters &cn) {
+    float closest = __builtin_inff();
+    uint32_t closest_i = 0, closest_tri = 0;
+    bool tri_hit = false, cyl_hit = false;
+    if (COUNT) cn.rays++;
+    intersect_spheres(r, closest, closest_i);
+    traverse_octree<STACK, COUNT>(S, r, closest, closest_tri, tri_hit, cn);
+
+    f3 cyl_n = F3(0.0f, 0.0f, 0.0f);
+    const float cyl_t = ray_cylinder(r, closest, cyl_n);
+    if (!is_inf(cyl_t)) { cyl_hit = true; closest = cyl_t; }
+
+    const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
+    const f3 pd1 = F3(U.portal_direction_1[0], U.portal_direction_1[1], U.portal_direction_1[2]);
+    const f3 pp2 = F3(U.portal_position_2[0], U.portal_position_2[1], U.portal_position_2[2]);
+    const f3 pd2 = F3(U.portal_direction_2[0], U.portal_direction_2[1], U.portal_direction_2[2]);
+    const float p1 = ray_portal(r, pp1, pd1, U.portal_width, U.portal_height, closest);
+    const float p2 = ray_portal(r, pp2, pd2, U.portal_width, U.portal_height, closest);
+
+    Hit h;
+    h.has_hit = false; h.position = F3(0, 0, 0); h.normal = F3(0, 0, 0); h.material_id = 0; h.portal_id = 0;
+    if (!is_inf(p1) && p1 < p2) {
+        h.has_hit = true; h.position = r.pos + r.dir * p1; h.normal = pd1; h.portal_id = 1;
+        if (tap) { tap->kind = RT_HIT_PORTAL_1; tap->slot = 0; tap->t = p1; }
+        return h;
+    }
+    if (!is_inf(p2) && p2 < p1) {
+        h.has_hit = true; h.position = r.pos + r.dir * p2; h.normal = pd2; h.portal_id = 2;
+        if (tap) { tap->kind = RT_HIT_PORTAL_2; tap->slot = 0; tap->t = p2; }
+        return h;
+    }
+    if (is_inf(closest)) {
+        if (tap) { tap->kind = RT_HIT_MISS; tap->slot = 0; tap->t = closest; }
+        return h;
+    }
+    h.has_hit = true;
+    h.position = r.pos + r.dir * closest;
+    if (cyl_hit) {
+        h.normal = cyl_n;
+        if (tap) { tap->kind = RT_HIT_CYLINDER; tap->slot = 0; tap->t = closest; }
+    } else if (tri_hit) {
+        const uint4 ind = *reinterpret_cast<const uint4 *>(S.tri_refs + 4 * (size_t)closest_tri);
+        const f3 a = load_xyz(S.vertices, ind.x), b = load_xyz(S.vertices, ind.y), c = load_xyz(S.vertices, ind.z);
+        const f3 n1 = load_xyz(S.normals, ind.x), n2 = load_xyz(S.normals, ind.y), n3 = load_xyz(S.normals, ind.z);
+        const f3 uvw = barycentric(h.position, a, b, c);
+        h.normal = (n1 * uvw.x + n2 * uvw.y) + n3 * uvw.z;
+        h.material_id = ind.w;
+        if (COUNT) cn.tri_shaded++;
+        if (tap) { tap->kind = RT_HIT_TRIANGLE; tap->slot = closest_tri; tap->t = closest; }
+    } else {
+        const float4 s = c_spheres[closest_i];
+        h.normal = normalize3(h.position - F3(s.x, s.y, s.z));
+        h.material_id = closest_i % 7u;
+        if (tap) { tap->kind = RT_HIT_SPHERE; tap->slot = closest_i; tap->t = closest; }
+    }
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// environment lookup (frag:662): RGBA8 cubemap, LINEAR, CLAMP_TO_EDGE, non-seamless, filtered in 8-bit fixed
+// point.  Major-axis selection uses UNORDERED comparisons and sign BITS (NaN directions from total internal
+// reflection reach this lookup: frag:639-650); on x86 an invalid operation yields a NEGATIVE quiet NaN, which
+// this hardware does not, so NaN components are given that sign here.
+// ------------------------------------------------------------------------------------------------
+DEVI int cvt_rne_x86(float f) {
+    if (!(__builtin_fabsf(f) < 2147483648.0f)) return (int)0x80000000;
+    return (int)__builtin_rintf(f);
+}
+DEVI float x86_nan(float v) { return v != v ? u2f(0xffc00000u) : v; }
+DEVI f3 sample_sky(const RtDeviceScene &S, f3 d) {
+    if (!S.sky) return F3(0.0f, 0.0f, 0.0f);
+    d = F3(x86_nan(d.x), x86_nan(d.y), x86_nan(d.z));
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    const bool x_over_y = !(ax <= ay);
+    const float maxxy = ax > ay ? ax : ay;
+    const bool z_sel = !(az < maxxy);
+    int face; float sc, tc, ma;
+    if (z_sel) { ma = d.z; const bool neg = (f2u(ma) >> 31) != 0; face = 4 + (neg ? 1 : 0); sc = neg ? -d.x : d.x; tc = -d.y; }
+    else if (x_over_y) { ma = d.x; const bool neg = (f2u(ma) >> 31) != 0; face = 0 + (neg ? 1 : 0); sc = neg ? d.z : -d.z; tc = -d.y; }
+    else { ma = d.y; const bool neg = (f2u(ma) >> 31) != 0; face = 2 + (neg ? 1 : 0); sc = d.x; tc = neg ? -d.z : d.z; }
+    const float ima = rcp_ieee(__builtin_fabsf(ma));
+    const float s = 0.5f * (sc * ima + 1.0f);
+    const float t = 0.5f * (tc * ima + 1.0f);
+    const int W = S.sky_w, H = S.sky_h;
+    const int Ui = (int)((uint32_t)cvt_rne_x86(s * (float)W * 256.0f) - 128u);
+    const int Vi = (int)((uint32_t)cvt_rne_x86(t * (float)H * 256.0f) - 128u);
+    int i0 = Ui >> 8, j0 = Vi >> 8;
+    const int wu = Ui & 255, wv = Vi & 255;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    i0 = min(max(i0, 0), W - 1); i1 = min(max(i1, 0), W - 1);
+    j0 = min(max(j0, 0), H - 1); j1 = min(max(j1, 0), H - 1);
+    const uchar4 *f = reinterpret_cast<const uchar4 *>(S.sky) + (size_t)face * W * H;
+    const uchar4 p00 = f[(size_t)j0 * W + i0], p10 = f[(size_t)j0 * W + i1], p01 = f[(size_t)j1 * W + i0], p11 = f[(size_t)j1 * W + i1];
+    auto lerp8 = [](int a, int b, int w) { return (a * (256 - w) + b * w + 128) >> 8; };
+    const int rr = lerp8(lerp8(p00.x, p10.x, wu), lerp8(p01.x, p11.x, wu), wv);
+    const int gg = lerp8(lerp8(p00.y, p10.y, wu), lerp8(p01.y, p11.y, wu), wv);
+    const int bb = lerp8(lerp8(p00.z, p10.z, wu), lerp8(p01.z, p11.z, wu), wv);
+    const float k = 1.0f / 255.0f;   // unorm8 -> float multiplies by the rounded reciprocal
+    return F3((float)rr * k, (float)gg * k, (float)bb * k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// path loop (frag:566-687)
+// ------------------------------------------------------------------------------------------------
+DEVI f3 mat_dir(const float *M, f3 v) {     // (M * vec4(v, 0)).xyz
+    return F3((M[0] * v.x + M[4] * v.y) + M[8] * v.z, (M[1] * v.x + M[5] * v.y) + M[9] * v.z, (M[2] * v.x + M[6] * v.y) + M[10] * v.z);
+}
+DEVI f3 mat_point(const float *M, f3 v) {   // (M * vec4(v, 1)).xyz
+    return F3(((M[0] * v.x + M[4] * v.y) + M[8] * v.z) + M[12], ((M[1] * v.x + M[5] * v.y) + M[9] * v.z) + M[13], ((M[2] * v.x + M[6] * v.y) + M[10] * v.z) + M[14]);
+}
+DEVI float nonlinear_depth(float d, float zn, float zf) { return div_ieee(zn * zf - d * zf, d * (zn - zf)); }   // frag:352-354
+DEVI float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+struct PixelOut { f3 color; float depth; PrimaryTap tap; uint32_t nrays; };
+
+template <int STACK, bool COUNT>
+DEVI void shade_pixel(const RtDeviceScene &S, const rt_uniforms &U, float ndc_x, float ndc_y, PixelOut &o, Counters &cn) {
+    const float *M = U.inv_view_proj_mat;
+    const f3 cam = F3(U.camera_position[0], U.camera_position[1], U.camera_position[2]);
+    // frag:676-677; evaluated ((M0*x + (-M2)) + M1*y) + M3
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) p[r] = ((M[r] * ndc_x + (-M[8 + r])) + M[4 + r] * ndc_y) + M[12 + r];
+    const f3 pp = F3(div_ieee(p[0], p[3]), div_ieee(p[1], p[3]), div_ieee(p[2], p[3]));
+    // frag:679-680
+    const float s1 = (float)base_hash(f2u(pp.x - U.time), f2u(pp.y - U.time)) / 4294967296.0f;
+    Seed seed;
+    seed.base = (float)base_hash(f2u(s1), f2u(s1)) / 4294967296.0f;
+    seed.k = 0;
+    // frag:682-684
+    const f3 jit = random_in_unit_sphere(seed);
+    Ray ray;
+    ray.pos = cam;
+    ray.dir = normalize3(pp - (cam + jit * U.blur_amount));
+    ray.inv = rcp3(ray.dir);
+    seed.rebase();
+
+    float depth = 1.0f;
+    f3 color = F3(1.0f, 1.0f, 1.0f);
+    o.nrays = 0;
+    o.tap.kind = RT_HIT_MISS; o.tap.slot = 0; o.tap.t = __builtin_inff();
+    const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
+    const f3 pd1 = F3(U.portal_direction_1[0], U.portal_direction_1[1], U.portal_direction_1[2]);
+    const f3 pp2 = F3(U.portal_position_2[0], U.portal_position_2[1], U.portal_position_2[2]);
+    const f3 pd2 = F3(U.portal_direction_2[0], U.portal_direction_2[1], U.portal_direction_2[2]);
+
+    for (uint32_t i = 0; i < U.max_recursion_limit; i++) {
+        const Hit h = find_intersection<STACK, COUNT>(S, U, ray, i == 0 ? &o.tap : nullptr, cn);
+        o.nrays++;
+        if (i == 0) {
+            if (h.has_hit) depth = clamp01(nonlinear_depth(length3(h.position - ray.pos), U.z_near, U.z_far));
+            else depth = clamp01(nonlinear_depth(U.z_far, U.z_near, U.z_far));
+        }
+        if (!h.has_hit) {
+            color = color * sample_sky(S, ray.dir);
+            break;
+        }
+        if (h.portal_id != 0) {
+            const bool one = h.portal_id == 1;
+            const f3 pd = one ? pd1 : pd2, psrc = one ? pp1 : pp2, pdst = one ? pp2 : pp1;
+            const float *PM = one ? U.portal_1_to_2 : U.portal_2_to_1;
+            color = color * (dot3(ray.dir, pd) < 0.0f ? 0.5f : 0.05f);
+            ray.pos = mat_point(PM, h.position - psrc) + pdst;
+            ray.dir = normalize3(mat_dir(PM, ray.dir));
+            ray.pos = ray.pos + ray.dir * 0.001f;
+        } else {
+            const Material m = c_materials[h.material_id];
+            const f3 mcol = F3(m.r, m.g, m.b);
+            if (m.type == LAMBERTIAN) {
+                const float F = fresnel_schlick_roughness(fmaxf(-dot3(ray.dir, h.normal), 0.0f), 0.04f, m.roughness);
+                ray.pos = h.position + h.normal * 0.001f;
+                if (hash1(seed) > F) {
+                    color = color * mcol;
+                    ray.dir = random_cos_weighted_hemisphere_direction(h.normal, seed);
+                } else {
+                    ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
+                }
+            } else if (m.type == METAL) {
+                ray.pos = h.position + h.normal * 0.001f;
+                ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
+                color = color * mcol;
+            } else {
+                float ri, cosine; f3 on;
+                const float dn = dot3(ray.dir, h.normal);
+                if (dn > 0.0f) {
+                    ri = m.refractive_index;
+                    cosine = sqrt_ieee(1.0f - ri * ri * (1.0f - dn * dn));
+                    on = -h.normal;
+                } else {
+                    ri = rcp_ieee(m.refractive_index);
+                    cosine = -dn;
+                    on = h.normal;
+                }
+                const f3 md = ray.dir + random_in_unit_sphere(seed) * m.roughness;
+                const f3 refr = normalize3(refract3(md, on, ri));
+                if (refr.x != 0.0f || refr.y != 0.0f || refr.z != 0.0f) {   // true for NaN (total internal reflection)
+                    const float rr = div_ieee(1.0f - ri, 1.0f + ri);
+                    const float F = fresnel_schlick_roughness(cosine, rr * rr, m.roughness);
+                    if (hash1(seed) > F) { ray.pos = h.position - on * 0.001f; ray.dir = refr; }
+                    else { ray.pos = h.position + on * 0.001f; ray.dir = normalize3(reflect3(md, on)); }
+                } else {
+                    ray.pos = h.position - on * 0.001f;
+                    ray.dir = normalize3(reflect3(md, on));
+                }
+            }
+        }
+        ray.inv = rcp3(ray.dir);
+        seed.rebase();
+    }
+    // frag:667-668
+    float c[3] = {color.x, color.y, color.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float x = fmaxf(0.0f, c[k] - 0.004f);
+        c[k] = div_ieee(x * (6.2f * x + 0.5f), x * (6.2f * x + 1.7f) + 0.06f);
+    }
+    o.color = F3(c[0], c[1], c[2]);
+    o.depth = depth;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame kernel: one lane per pixel, one wave per 8x8 pixel tile, 4 waves (a 16x16 tile) per workgroup.
+// Workgroups are renumbered so that the 8 round-robin dispatch classes (blockIdx % 8, the workgroups that share an
+// XCD's L2) each own a contiguous range of tiles.
+// ------------------------------------------------------------------------------------------------
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(256) void render_kernel(RtDeviceScene S, RtLaunch L) {
+    const uint32_t tiles_x = (L.width + 15u) / 16u;
+    const uint32_t tiles_y = (L.n_local_rows + 15u) / 16u;
+    const uint32_t nwg = tiles_x * tiles_y;
+    uint32_t bid = blockIdx.x;
+    {   // bijective XCD-class remap
+        const uint32_t q = nwg / 8u, rem = nwg % 8u, cls = bid % 8u, idx = bid / 8u;
+        bid = (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;
+    }
+    const uint32_t tile_x = bid % tiles_x, tile_y = bid / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = tile_x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t lr = tile_y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    // local row -> frame row: strip j of this part is global strip j*parts + part
+    const uint32_t y = ((lr / L.band_rows) * L.band_parts + L.band_part) * L.band_rows + (lr % L.band_rows);
+    const bool active = x < L.width && lr < L.n_local_rows && y < L.height;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    if (active) {
+        const size_t pi = (size_t)y * L.width + x;
+        const float nx = L.ndc_x ? L.ndc_x[pi] : div_ieee(2.0f * ((float)x + 0.5f), (float)L.width) - 1.0f;
+        const float ny = L.ndc_y ? L.ndc_y[pi] : div_ieee(2.0f * ((float)y + 0.5f), (float)L.height) - 1.0f;
+        PixelOut o;
+        shade_pixel<STACK, COUNT>(S, L.u, nx, ny, o, cn);
+        float4 *dstp = reinterpret_cast<float4 *>(L.color) + pi;
+        float4 out;
+        if (L.blend) {   // App.cpp:49,104: dst = src*(1/n) + dst*(1 - 1/n) on all four channels (src alpha = 0)
+            const float a = rcp_ieee((float)L.accum_index), ia = 1.0f - a;
+            const float4 dst = *dstp;
+            out.x = o.color.x * a + dst.x * ia; out.y = o.color.y * a + dst.y * ia; out.z = o.color.z * a + dst.z * ia; out.w = 0.0f * a + dst.w * ia;
+        } else {
+            out.x = o.color.x; out.y = o.color.y; out.z = o.color.z; out.w = 0.0f;
+        }
+        *dstp = out;
+        if (L.depth) L.depth[pi] = o.depth;
+        if (L.hit_kind) L.hit_kind[pi] = o.tap.kind;
+        if (L.hit_slot) L.hit_slot[pi] = o.tap.slot;
+        if (L.hit_t) L.hit_t[pi] = o.tap.t;
+        if (L.n_rays) L.n_rays[pi] = o.nrays;
+    }
+    if (COUNT && L.counters) {
+        atomicAdd(&L.counters[0], (unsigned long long)cn.rays);
+        atomicAdd(&L.counters[1], (unsigned long long)cn.pops);
+        atomicAdd(&L.counters[2], (unsigned long long)cn.tri_tests);
+        atomicAdd(&L.counters[3], (unsigned long long)cn.box_tests);
+        atomicAdd(&L.counters[4], (unsigned long long)cn.tri_shaded);
+        atomicAdd(&L.counters[5], (unsigned long long)cn.entered);
+    }
+}
+
+template <int STACK>
+int launch_with_stack(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid) {
+    if (L.counters) hipLaunchKernelGGL((render_kernel<STACK, true>), grid, dim3(256), 0, st, S, L);
+    else hipLaunchKernelGGL((render_kernel<STACK, false>), grid, dim3(256), 0, st, S, L);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, void *stream, const char **err) {
+    const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
+    if (tiles_x == 0 || tiles_y == 0) return 0;
+    const dim3 grid(tiles_x * tiles_y);
+    hipStream_t st = (hipStream_t)stream;
+    // a visit pushes at most 8 children and pops one: the stack never exceeds 7*levels + 1 entries
+    const uint32_t need = 7u * (S.max_depth + 1u) + 1u;
+    int rc;
+    if (need <= 64) rc = launch_with_stack<64>(S, L, st, grid);
+    else if (need <= 160) rc = launch_with_stack<160>(S, L, st, grid);
+    else rc = launch_with_stack<7 * (RT_MAX_TREE_DEPTH + 1) + 1>(S, L, st, grid);
+    if (rc != 0) { if (err) *err = hipGetErrorString((hipError_t)rc); return rc; }
+    return 0;
+}

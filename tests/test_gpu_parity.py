@@ -1,0 +1,134 @@
+"""GPU parity: the HIP render pass (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact primary-hit kind / slot / t / segment counts; colour bit-exact (the stated tolerance of
+max-abs <= 1/255 on >= 99.9 % of pixels is asserted as the fallback bar and PSNR is reported)."""
+import math
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api, scenes
+from raytracer_amd.camera import Camera
+from raytracer_amd.params import Uniforms
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def compare(o, g, name, exact=True):
+    rep = {}
+    for k in ("kind", "slot", "nrays"):
+        rep[k] = float((o[k] == g[k]).mean())
+    rep["t"] = float((bits(o["t"]) == bits(g["t"])).mean())
+    rep["depth"] = float((bits(o["depth"]) == bits(g["depth"])).mean())
+    ceq = (bits(o["rgba"]) == bits(g["rgba"])).all(-1)
+    rep["colour_bits"] = float(ceq.mean())
+    d = np.abs(o["rgba"][..., :3].astype(np.float64) - g["rgba"][..., :3].astype(np.float64))
+    d = np.where(np.isnan(d), np.inf, d)
+    rep["within_1_255"] = float((d.max(-1) <= 1.0 / 255.0).mean())
+    mse = float(np.mean(np.minimum(d, 1.0) ** 2))
+    rep["psnr_db"] = float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+    print(name, rep)
+    assert rep["kind"] == 1.0 and rep["slot"] == 1.0 and rep["t"] == 1.0, (name, rep)   # hit IDs: bit-exact
+    assert rep["nrays"] == 1.0, (name, rep)
+    assert rep["within_1_255"] >= 0.999, (name, rep)                                     # colour tolerance bar
+    if exact:
+        assert rep["colour_bits"] == 1.0 and rep["depth"] == 1.0, (name, rep)
+    return rep
+
+
+VIEWS = {
+    "default": dict(cam=Camera(aspect=1.0)),
+    "wide": dict(cam=Camera(aspect=2.0), size=(512, 256)),
+    "portal": dict(cam=Camera(eye=(3.0, 2.0, 3.0), at=(7.0, 2.0, 3.0), aspect=1.0)),
+    "portal2": dict(cam=Camera(eye=(9.5, 2.2, 6.5), at=(7.0, 1.5, 4.0), aspect=1.0)),
+    "glass": dict(cam=Camera(eye=(-2.0, 2.5, 3.0), at=(-4.0, 2.0, 0.0), aspect=1.0)),
+    "close": dict(cam=Camera(eye=(0.5, 2.5, 1.0), at=(-0.3, 1.9, 0.0), aspect=1.0)),
+    "time": dict(cam=Camera(aspect=1.0), kw=dict(time=3.7)),
+    "topdown": dict(cam=Camera(eye=(0.1, 9.0, 0.1), at=(0.0, 0.0, 0.0), aspect=1.0)),
+    "maxrec2": dict(cam=Camera(aspect=1.0), kw=dict(max_recursion_limit=2)),
+    "maxrec8": dict(cam=Camera(aspect=1.0), kw=dict(max_recursion_limit=8, blur_amount=0.01)),
+}
+
+
+@pytest.fixture(scope="module")
+def bunny_pair(bunny_octree, test_sky):
+    from oracle import oracle
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(test_sky)
+    osc = oracle.OracleScene(bunny_octree.as_dict(), test_sky)
+    yield sc, osc
+    sc.close()
+
+
+@pytest.mark.parametrize("view", list(VIEWS))
+def test_bunny_views_bit_exact(bunny_pair, view):
+    sc, osc = bunny_pair
+    v = VIEWS[view]
+    w, h = v.get("size", (256, 256))
+    u = Uniforms.from_camera(v["cam"], **v.get("kw", {})).pack()
+    compare(osc.render(u, w, h), sc.render(u, w, h), view)
+
+
+def test_progressive_accumulation(bunny_pair):
+    sc, osc = bunny_pair
+    w = h = 128
+    acc_o = acc_g = None
+    for k, t in enumerate(np.array([0.0, 1 / 60, 2 / 60, 0.5], np.float32)):
+        u = Uniforms.from_camera(Camera(aspect=1.0), time=float(t)).pack()
+        acc_o = osc.render(u, w, h, accum_index=k + 1, rgba=acc_o)["rgba"]
+        acc_g = sc.render(u, w, h, accum_index=k + 1, color=acc_g)["rgba"]
+    assert np.array_equal(bits(acc_o), bits(acc_g))
+
+
+def test_bands_equal_full_frame(bunny_pair):
+    sc, _ = bunny_pair
+    w, h = 256, 200   # height not a multiple of the strip
+    u = Uniforms.from_camera(Camera(aspect=w / h)).pack()
+    full = sc.render(u, w, h)
+    for parts in (2, 3, 8):
+        col = np.zeros((h, w, 4), np.float32)
+        planes = None
+        for p in range(parts):
+            r = sc.render(u, w, h, color=col, band=(16, parts, p), planes=False)
+            col = r["rgba"]
+        assert np.array_equal(bits(col), bits(full["rgba"])), parts
+
+
+def test_no_mesh_scene(test_sky):
+    from oracle import oracle
+    d = dict(vertices=np.zeros((0, 4), np.float32), normals=np.zeros((0, 4), np.float32), tri_refs=np.zeros((0, 4), np.uint32), nodes=np.zeros((0,), np.uint32),
+             bounds_min=np.zeros(3, np.float32), bounds_max=np.zeros(3, np.float32))
+    sc = api.Scene.from_dict(d)
+    sc.set_skybox(test_sky)
+    u = Uniforms.from_camera(Camera(aspect=1.0)).pack()
+    d1 = dict(d); d1["vertices"] = np.zeros((1, 4), np.float32); d1["normals"] = np.zeros((1, 4), np.float32); d1["tri_refs"] = np.zeros((1, 4), np.uint32)
+    compare(oracle.OracleScene(d1, test_sky).render(u, 128, 128), sc.render(u, 128, 128), "no-mesh")
+    sc.close()
+
+
+def test_synthetic_scene_all_materials(test_sky):
+    from oracle import oracle
+    oc = scenes.small_test_scene()
+    sc = api.Scene.from_octree(oc)
+    sc.set_skybox(test_sky)
+    osc = oracle.OracleScene(oc.as_dict(), test_sky)
+    for cam in (Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=1.0), Camera(eye=(0.0, 1.5, 0.2), at=(1.0, 1.6, 0.0), aspect=1.0)):
+        u = Uniforms.from_camera(cam).pack()
+        compare(osc.render(u, 256, 256), sc.render(u, 256, 256), "synthetic")
+    sc.close()
+
+
+def test_counters_match_oracle(bunny_pair):
+    sc, osc = bunny_pair
+    u = Uniforms.from_camera(Camera(aspect=1.0)).pack()
+    sc.set_counting(True)
+    sc.render(u, 256, 256)
+    st = sc.stats()
+    sc.set_counting(False)
+    oc = osc.render(u, 256, 256)["counters"]
+    for k in ("rays", "node_pops", "triangle_tests", "child_box_tests", "triangle_hits_shaded", "rays_entering_octree"):
+        assert st[k] == oc[k], (k, st, oc)
