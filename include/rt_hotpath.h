@@ -70,7 +70,10 @@ typedef struct rt_frame {
     /* Screen-space band selection for multi-GPU rendering: rows are cut into strips of `band_rows` rows and strip s
      * is rendered iff s % band_parts == band_part.  band_parts = 1 renders every row. */
     uint32_t band_rows, band_parts, band_part;
-    uint32_t reserved0;
+    /* 0: target planes are full frames addressed [y][x]; 1: planes hold only this part's rows, packed in band order
+     * ([local_row][x] with local_row = (strip / band_parts) * band_rows + y % band_rows) -- the buffer a rank sends
+     * when the bands of several GPUs are gathered.  ndc_x / ndc_y stay full-frame. */
+    uint32_t compact_rows;
     /* Optional per-pixel NDC of the interpolated varying vs_out_ndc_coord (ray_tracer.vert:5-13), [height][width]
      * floats each, in the memory space of rt_target.memory; NULL = closed form 2*(i+0.5)/size - 1. */
     const float *ndc_x;
@@ -79,8 +82,8 @@ typedef struct rt_frame {
 } rt_frame;
 
 /* Render target: the colour attachment (RGBA32F, linear, Framebuffer.cpp:6) and optional extra planes.
- * All planes are [height][width] (x4 for colour), always addressed by full-frame pixel index even when only a
- * band is rendered; pixels outside the band are left untouched. */
+ * All planes are [height][width] (x4 for colour) addressed by full-frame pixel index (pixels outside the rendered
+ * band are left untouched), or, with rt_frame.compact_rows = 1, [rt_band_row_count()][width] holding only the band. */
 typedef struct rt_target {
     int32_t memory;                /* RT_MEM_HOST or RT_MEM_DEVICE: where every pointer below (and ndc_x/ndc_y) lives */
     int32_t sync;                  /* 1: return after the frame is complete; 0 (device memory only): return after enqueue */
@@ -123,6 +126,9 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert,
  * Without a skybox texture() returns 0 like an unbound texture. */
 int rt_skybox_set(rt_scene *scene, const uint8_t *const faces[6], int w, int h);
 int rt_render(rt_scene *scene, const rt_frame *frame, const rt_target *target);
+/* Number of rows a compact band buffer holds for this frame's band selection (whole strips; the last strip may
+ * extend past `height`, those rows are never written). */
+uint32_t rt_band_row_count(const rt_frame *frame);
 int rt_scene_stats(rt_scene *scene, rt_stats *out);   /* counters of the last rt_render with sync = 1 or after a stream sync */
 /* Enables (1) / disables (0) work counters for subsequent renders of this scene (default off: counting costs time). */
 int rt_scene_set_counting(rt_scene *scene, int enabled);

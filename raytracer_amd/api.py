@@ -28,7 +28,7 @@ RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = range(6)
 
 EXPORTED_SYMBOLS = [
-    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_scene_stats",
+    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_band_row_count", "rt_scene_stats",
     "rt_scene_set_counting", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_free",
 ]
 
@@ -45,7 +45,7 @@ class rt_uniforms(C.Structure):
 
 class rt_frame(C.Structure):
     _fields_ = [("u", rt_uniforms), ("width", C.c_uint32), ("height", C.c_uint32), ("accum_index", C.c_uint32), ("blend", C.c_uint32),
-                ("band_rows", C.c_uint32), ("band_parts", C.c_uint32), ("band_part", C.c_uint32), ("reserved0", C.c_uint32),
+                ("band_rows", C.c_uint32), ("band_parts", C.c_uint32), ("band_part", C.c_uint32), ("compact_rows", C.c_uint32),
                 ("ndc_x", C.c_void_p), ("ndc_y", C.c_void_p), ("stream", C.c_void_p)]
 
 
@@ -86,6 +86,8 @@ def lib():
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.rt_skybox_set.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_frame), C.POINTER(rt_target)]
+        L.rt_band_row_count.argtypes = [C.POINTER(rt_frame)]
+        L.rt_band_row_count.restype = C.c_uint32
         L.rt_scene_stats.argtypes = [C.c_void_p, C.POINTER(rt_stats)]
         L.rt_scene_set_counting.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
@@ -265,7 +267,11 @@ class Scene:
             pass
 
 
-def make_frame(uniforms70: np.ndarray, width: int, height: int, *, accum_index: int = 1, blend: bool = True, band=(16, 1, 0), stream: int | None = None) -> rt_frame:
+def band_row_count(frame: rt_frame) -> int:
+    return int(lib().rt_band_row_count(C.byref(frame)))
+
+
+def make_frame(uniforms70: np.ndarray, width: int, height: int, *, accum_index: int = 1, blend: bool = True, band=(16, 1, 0), stream: int | None = None, compact: bool = False) -> rt_frame:
     u = np.ascontiguousarray(uniforms70, np.float32)
     if u.size != 70:
         raise RtError(RT_EINVAL, "uniform block must have 70 words")
@@ -273,6 +279,7 @@ def make_frame(uniforms70: np.ndarray, width: int, height: int, *, accum_index: 
     C.memmove(C.byref(fr.u), u.ctypes.data, 280)
     fr.width, fr.height, fr.accum_index, fr.blend = width, height, accum_index, int(blend)
     fr.band_rows, fr.band_parts, fr.band_part = band
+    fr.compact_rows = int(compact)
     fr.stream = stream
     return fr
 

@@ -170,11 +170,6 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
         if (t[0] >= n_vert || t[1] >= n_vert || t[2] >= n_vert) return fail(RT_ESCENE, "triangle reference %zu indexes vertex >= %zu", i, n_vert);
         if (t[3] >= RT_NUM_MATERIALS) return fail(RT_ESCENE, "triangle reference %zu has material id %u >= %u", i, t[3], RT_NUM_MATERIALS);
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
-    int dev = g_device;
-    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return fail(RT_ENODEVICE, "hipGetDevice failed"); }
-
     std::vector<RtNodeRec> recs;
     std::vector<RtTriRec> tris(n_ref);
     uint32_t max_depth = 0;
@@ -192,6 +187,11 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
             r.pad[0] = r.pad[1] = r.pad[2] = 0;
         }
     }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+    int dev = g_device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return fail(RT_ENODEVICE, "hipGetDevice failed"); }
 
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_ENOMEM, "out of host memory");
@@ -255,6 +255,14 @@ int rt_scene_stats(rt_scene *s, rt_stats *out) {
     return RT_OK;
 }
 
+static uint32_t band_rows_of(const rt_frame *f) {
+    if (!f || f->band_rows == 0 || f->band_parts == 0 || f->band_part >= f->band_parts) return 0;
+    const uint32_t n_strips = (f->height + f->band_rows - 1) / f->band_rows;
+    const uint32_t mine = n_strips > f->band_part ? (n_strips - f->band_part + f->band_parts - 1) / f->band_parts : 0;
+    return mine * f->band_rows;
+}
+uint32_t rt_band_row_count(const rt_frame *f) { return band_rows_of(f); }
+
 int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
     if (!s || !f || !t) return fail(RT_EINVAL, "null argument");
     if (!t->color) return fail(RT_EINVAL, "target colour plane is null");
@@ -268,18 +276,18 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
     if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
     hipStream_t st = (hipStream_t)f->stream;
 
-    // rows owned by this part: full strips plus the clipped last one
-    const uint32_t n_strips = (f->height + f->band_rows - 1) / f->band_rows;
-    const uint32_t my_strips = n_strips > f->band_part ? (n_strips - f->band_part + f->band_parts - 1) / f->band_parts : 0;
+    if (f->compact_rows > 1) return fail(RT_EINVAL, "compact_rows must be 0 or 1");
     RtLaunch L{};
     L.u = f->u;
     L.width = f->width; L.height = f->height; L.accum_index = f->accum_index; L.blend = f->blend ? 1u : 0u;
     L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
-    L.n_local_rows = my_strips * f->band_rows;
+    L.n_local_rows = band_rows_of(f);   // rows owned by this part: whole strips, the last one clipped by the kernel
+    L.compact_rows = f->compact_rows;
     L.counters = s->counting ? s->d_counters : nullptr;
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
 
-    const size_t px = (size_t)f->width * f->height;
+    const size_t px = (size_t)f->width * f->height;                                            // ndc planes
+    const size_t tpx = f->compact_rows ? (size_t)f->width * L.n_local_rows : px;              // target planes
     const char *kerr = nullptr;
     if (t->memory == RT_MEM_DEVICE) {
         L.ndc_x = f->ndc_x; L.ndc_y = f->ndc_y;
@@ -289,27 +297,27 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
         return RT_OK;
     }
     // Host target: stage through device buffers owned by the scene.
-    if (s->s_pixels != px) {
+    if (s->s_pixels != px + tpx) {
         free_staging(s);
-        HIP_TRY(hipMalloc(&s->s_color, px * 16)); HIP_TRY(hipMalloc(&s->s_depth, px * 4)); HIP_TRY(hipMalloc(&s->s_kind, px * 4));
-        HIP_TRY(hipMalloc(&s->s_slot, px * 4)); HIP_TRY(hipMalloc(&s->s_t, px * 4)); HIP_TRY(hipMalloc(&s->s_nrays, px * 4));
+        HIP_TRY(hipMalloc(&s->s_color, (tpx ? tpx : 1) * 16)); HIP_TRY(hipMalloc(&s->s_depth, (tpx ? tpx : 1) * 4)); HIP_TRY(hipMalloc(&s->s_kind, (tpx ? tpx : 1) * 4));
+        HIP_TRY(hipMalloc(&s->s_slot, (tpx ? tpx : 1) * 4)); HIP_TRY(hipMalloc(&s->s_t, (tpx ? tpx : 1) * 4)); HIP_TRY(hipMalloc(&s->s_nrays, (tpx ? tpx : 1) * 4));
         HIP_TRY(hipMalloc(&s->s_ndcx, px * 4)); HIP_TRY(hipMalloc(&s->s_ndcy, px * 4));
-        s->s_pixels = px;
+        s->s_pixels = px + tpx;
     }
-    HIP_TRY(hipMemcpyAsync(s->s_color, t->color, px * 16, hipMemcpyHostToDevice, st));   // read-modify-write target (blend) and untouched bands
+    HIP_TRY(hipMemcpyAsync(s->s_color, t->color, tpx * 16, hipMemcpyHostToDevice, st));   // read-modify-write target (blend) and untouched bands
     if (f->ndc_x) {
         HIP_TRY(hipMemcpyAsync(s->s_ndcx, f->ndc_x, px * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(s->s_ndcy, f->ndc_y, px * 4, hipMemcpyHostToDevice, st));
         L.ndc_x = (const float *)s->s_ndcx; L.ndc_y = (const float *)s->s_ndcy;
     }
     struct Plane { void *host; void *dev; size_t bytes; };
-    Plane planes[] = {{t->depth, s->s_depth, px * 4}, {t->hit_kind, s->s_kind, px * 4}, {t->hit_slot, s->s_slot, px * 4}, {t->hit_t, s->s_t, px * 4}, {t->n_rays, s->s_nrays, px * 4}};
+    Plane planes[] = {{t->depth, s->s_depth, tpx * 4}, {t->hit_kind, s->s_kind, tpx * 4}, {t->hit_slot, s->s_slot, tpx * 4}, {t->hit_t, s->s_t, tpx * 4}, {t->n_rays, s->s_nrays, tpx * 4}};
     for (Plane &p : planes) if (p.host) HIP_TRY(hipMemcpyAsync(p.dev, p.host, p.bytes, hipMemcpyHostToDevice, st));
     L.color = (float *)s->s_color;
     L.depth = t->depth ? (float *)s->s_depth : nullptr; L.hit_kind = t->hit_kind ? (uint32_t *)s->s_kind : nullptr;
     L.hit_slot = t->hit_slot ? (uint32_t *)s->s_slot : nullptr; L.hit_t = t->hit_t ? (float *)s->s_t : nullptr; L.n_rays = t->n_rays ? (uint32_t *)s->s_nrays : nullptr;
     if (rt_launch_render(s->d, L, st, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
-    HIP_TRY(hipMemcpyAsync(t->color, s->s_color, px * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t->color, s->s_color, tpx * 16, hipMemcpyDeviceToHost, st));
     for (Plane &p : planes) if (p.host) HIP_TRY(hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return RT_OK;

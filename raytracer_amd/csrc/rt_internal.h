@@ -45,6 +45,7 @@ struct RtLaunch {
     rt_uniforms u;
     uint32_t width, height, accum_index, blend;
     uint32_t band_rows, band_parts, band_part, n_local_rows;
+    uint32_t compact_rows;
     const float *ndc_x, *ndc_y;
     float *color, *depth, *hit_t;
     uint32_t *hit_kind, *hit_slot, *n_rays;

@@ -430,9 +430,9 @@ DEVI f3 sample_sky(const RtDeviceScene &S, f3 d) {
     if (z_sel) { ma = d.z; const bool neg = (f2u(ma) >> 31) != 0; face = 4 + (neg ? 1 : 0); sc = neg ? -d.x : d.x; tc = -d.y; }
     else if (x_over_y) { ma = d.x; const bool neg = (f2u(ma) >> 31) != 0; face = 0 + (neg ? 1 : 0); sc = neg ? d.z : -d.z; tc = -d.y; }
     else { ma = d.y; const bool neg = (f2u(ma) >> 31) != 0; face = 2 + (neg ? 1 : 0); sc = d.x; tc = neg ? -d.z : d.z; }
-    const float ima = rcp_ieee(__builtin_fabsf(ma));
-    const float s = 0.5f * (sc * ima + 1.0f);
-    const float t = 0.5f * (tc * ima + 1.0f);
+    const float ima = div_ieee(0.5f, __builtin_fabsf(ma));   // projection: coord * (0.5 / |ma|) + 0.5
+    const float s = ima * sc + 0.5f;
+    const float t = ima * tc + 0.5f;
     const int W = S.sky_w, H = S.sky_h;
     const int Ui = (int)((uint32_t)cvt_rne_x86(s * (float)W * 256.0f) - 128u);
     const int Vi = (int)((uint32_t)cvt_rne_x86(t * (float)H * 256.0f) - 128u);
@@ -594,9 +594,10 @@ __global__ __launch_bounds__(256) void render_kernel(RtDeviceScene S, RtLaunch L
     const bool active = x < L.width && lr < L.n_local_rows && y < L.height;
     Counters cn = {0, 0, 0, 0, 0, 0};
     if (active) {
-        const size_t pi = (size_t)y * L.width + x;
-        const float nx = L.ndc_x ? L.ndc_x[pi] : div_ieee(2.0f * ((float)x + 0.5f), (float)L.width) - 1.0f;
-        const float ny = L.ndc_y ? L.ndc_y[pi] : div_ieee(2.0f * ((float)y + 0.5f), (float)L.height) - 1.0f;
+        const size_t fi = (size_t)y * L.width + x;                                  // full-frame pixel index
+        const size_t pi = L.compact_rows ? (size_t)lr * L.width + x : fi;          // index into the target planes
+        const float nx = L.ndc_x ? L.ndc_x[fi] : div_ieee(2.0f * ((float)x + 0.5f), (float)L.width) - 1.0f;
+        const float ny = L.ndc_y ? L.ndc_y[fi] : div_ieee(2.0f * ((float)y + 0.5f), (float)L.height) - 1.0f;
         PixelOut o;
         shade_pixel<STACK, COUNT>(S, L.u, nx, ny, o, cn);
         float4 *dstp = reinterpret_cast<float4 *>(L.color) + pi;

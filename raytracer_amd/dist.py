@@ -1,0 +1,86 @@
+"""Multi-GPU rendering: one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+Pixels are independent in the reference's shader (/root/reference/app/assets/ray_tracer.frag has no inter-pixel
+communication; blending is per pixel), so the frame shards by screen-space bands: rows are cut into strips of
+`band_rows` rows that are dealt round-robin to the ranks (cost per pixel varies by more than 10x between sky and
+mesh, so contiguous bands would be unbalanced).  Each rank renders its strips into a compact buffer; progressive
+accumulation stays local to the band.  Two collectives exist, both outside the per-pixel data path:
+
+  broadcast_scene   once per scene: the four scene arrays, bounds and the skybox from rank 0
+  gather_frame      once per presented frame: every rank's compact band buffer to rank 0, which re-interleaves them
+
+The functions work on any backend/device, which is how the logic is tested on CPU with gloo.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def n_strips(height: int, band_rows: int) -> int:
+    return (height + band_rows - 1) // band_rows
+
+
+def local_row_count(height: int, band_rows: int, parts: int, part: int) -> int:
+    """Rows of the compact buffer of `part` (whole strips) -- same rule as rt_band_row_count()."""
+    s = n_strips(height, band_rows)
+    mine = (s - part + parts - 1) // parts if s > part else 0
+    return mine * band_rows
+
+
+def padded_row_count(height: int, band_rows: int, parts: int) -> int:
+    """Row count every rank's send buffer is padded to (rank 0 owns the most strips)."""
+    return local_row_count(height, band_rows, parts, 0)
+
+
+def local_to_frame_rows(height: int, band_rows: int, parts: int, part: int) -> np.ndarray:
+    """Frame row of every compact row of `part` (-1 for rows of a strip that lies beyond the frame)."""
+    n = local_row_count(height, band_rows, parts, part)
+    lr = np.arange(n)
+    y = ((lr // band_rows) * parts + part) * band_rows + lr % band_rows
+    return np.where(y < height, y, -1)
+
+
+def broadcast_scene(arrays: dict | None, device: torch.device, src: int = 0) -> dict:
+    """Broadcast a scene dict (vertices, normals, tri_refs, nodes, bounds_min, bounds_max[, sky]) from `src`.
+    Non-source ranks pass None.  Returns numpy arrays on every rank."""
+    rank = dist.get_rank()
+    keys = ["vertices", "normals", "tri_refs", "nodes", "bounds_min", "bounds_max", "sky"]
+    dtypes = {"vertices": np.float32, "normals": np.float32, "tri_refs": np.uint32, "nodes": np.uint32, "bounds_min": np.float32, "bounds_max": np.float32, "sky": np.uint8}
+    meta = [None]
+    if rank == src:
+        meta = [{k: tuple(np.asarray(arrays[k]).shape) for k in keys if arrays.get(k) is not None}]
+    dist.broadcast_object_list(meta, src=src)
+    out = {}
+    for k in keys:
+        if k not in meta[0]:
+            continue
+        shape = meta[0][k]
+        nbytes = int(np.prod(shape)) * np.dtype(dtypes[k]).itemsize
+        if rank == src:
+            buf = torch.from_numpy(np.ascontiguousarray(arrays[k], dtypes[k]).view(np.uint8).reshape(-1).copy()).to(device)
+        else:
+            buf = torch.empty(max(nbytes, 0), dtype=torch.uint8, device=device)
+        if nbytes:
+            dist.broadcast(buf, src=src)
+        out[k] = buf.cpu().numpy().view(dtypes[k]).reshape(shape)
+    return out
+
+
+def gather_frame(local: torch.Tensor, height: int, band_rows: int, dst: int = 0):
+    """Gather compact band buffers ([padded_rows, width, C] on every rank) to `dst` and re-interleave them into a
+    [height, width, C] frame.  Returns the frame on `dst`, None elsewhere."""
+    parts, rank = dist.get_world_size(), dist.get_rank()
+    pad = padded_row_count(height, band_rows, parts)
+    assert local.shape[0] == pad, (local.shape, pad)
+    bufs = [torch.empty_like(local) for _ in range(parts)] if rank == dst else None
+    dist.gather(local, bufs, dst=dst)
+    if rank != dst:
+        return None
+    # [part, strip_local, band_rows, W, C] -> [strip_local, part, band_rows, W, C] -> rows in frame order
+    stack = torch.stack(bufs, 0)
+    w, c = local.shape[1], local.shape[2]
+    s_local = pad // band_rows
+    frame = stack.view(parts, s_local, band_rows, w, c).permute(1, 0, 2, 3, 4).reshape(s_local * parts * band_rows, w, c)
+    return frame[:height].contiguous()
