@@ -132,6 +132,15 @@ uint32_t rt_band_row_count(const rt_frame *frame);
 int rt_scene_stats(rt_scene *scene, rt_stats *out);   /* counters of the last rt_render with sync = 1 or after a stream sync */
 /* Enables (1) / disables (0) work counters for subsequent renders of this scene (default off: counting costs time). */
 int rt_scene_set_counting(rt_scene *scene, int enabled);
+/* Selects how a frame is executed (results are identical): RT_PIPELINE_WAVEFRONT (default) runs one pass per path
+ * depth -- sphere tests, a persistent octree-traversal kernel fed from a queue, shading with compaction of the
+ * surviving paths; RT_PIPELINE_MEGAKERNEL traces a pixel's whole path in one lane of one kernel. */
+enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1 };
+int rt_scene_set_pipeline(rt_scene *scene, int pipeline);
+/* Wavefront pipeline only: a frame is rendered as up to n (1..8, default 4) interleaved sub-frames whose kernel
+ * chains run on separate internal streams, forked from and joined to rt_frame.stream, so that the sparse end of one
+ * chain overlaps the dense kernels of another.  Results do not depend on n. */
+int rt_scene_set_subframes(rt_scene *scene, int n);
 int rt_scene_destroy(rt_scene *scene);
 
 /* Host-side scene build: mirrors of the reference's Mesh and Octree classes --------------------------------- */

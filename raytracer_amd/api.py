@@ -21,7 +21,7 @@ import numpy as np
 from .params import Uniforms
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hotpath.so")
+LIB_PATH = os.environ.get("RT_HOTPATH_LIB", os.path.join(_HERE, "librt_hotpath.so"))   # override: development builds
 
 RT_OK, RT_EINVAL, RT_ESCENE, RT_ENODEVICE, RT_ENOMEM, RT_ELIMIT = range(6)
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
@@ -29,7 +29,7 @@ HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = r
 
 EXPORTED_SYMBOLS = [
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_band_row_count", "rt_scene_stats",
-    "rt_scene_set_counting", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_free",
+    "rt_scene_set_counting", "rt_scene_set_pipeline", "rt_scene_set_subframes", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_free",
 ]
 
 
@@ -90,6 +90,8 @@ def lib():
         L.rt_band_row_count.restype = C.c_uint32
         L.rt_scene_stats.argtypes = [C.c_void_p, C.POINTER(rt_stats)]
         L.rt_scene_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_set_pipeline.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_set_subframes.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_mesh_load_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
         L.rt_mesh_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
@@ -225,6 +227,13 @@ class Scene:
 
     def set_counting(self, enabled: bool):
         _check(lib().rt_scene_set_counting(self._h, int(enabled)))
+
+    def set_pipeline(self, name: str):
+        """'wavefront' (default) or 'megakernel'; results are identical."""
+        _check(lib().rt_scene_set_pipeline(self._h, {"megakernel": 0, "wavefront": 1}[name]))
+
+    def set_subframes(self, n: int):
+        _check(lib().rt_scene_set_subframes(self._h, n))
 
     def stats(self) -> dict:
         s = rt_stats()

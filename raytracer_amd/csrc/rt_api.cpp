@@ -52,6 +52,18 @@ struct rt_scene {
     // staging for host-memory targets
     void *s_color = nullptr, *s_depth = nullptr, *s_kind = nullptr, *s_slot = nullptr, *s_t = nullptr, *s_nrays = nullptr, *s_ndcx = nullptr, *s_ndcy = nullptr;
     size_t s_pixels = 0;
+    // wavefront pipeline: a frame is cut into up to RT_MAX_SUBFRAMES interleaved sub-frames that run as independent
+    // kernel chains on their own streams, so that the sparse tail of one chain overlaps the dense kernels of another
+    int pipeline = RT_PIPELINE_WAVEFRONT;
+    int subframes = 4;
+    struct Sub {
+        RtWorkspace ws{};
+        void *block = nullptr;
+        size_t slots = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    } sub[RT_MAX_SUBFRAMES];
+    hipEvent_t fork_ev = nullptr;
 };
 
 namespace {
@@ -68,29 +80,26 @@ void free_staging(rt_scene *s) {
     s->s_pixels = 0;
 }
 
-// Walks the reference node words (Octree.cpp:44-75; read by the shader at frag:460-464,481-484) from the root,
-// checks every offset the shader would dereference, and emits one 64-byte record per visited node in visit order.
+// Walks the reference node words (Octree.cpp:44-75; read by the shader at frag:460-464,481-484) breadth-first from
+// the root, checks every offset the shader would dereference, and emits one 64-byte record per visited node.
 int flatten_nodes(const uint32_t *words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3],
                   std::vector<RtNodeRec> &out, uint32_t &max_depth) {
     out.clear();
     max_depth = 0;
     if (n_words == 0) return RT_OK;
     if (n_words < 2) return fail(RT_ESCENE, "node buffer has %zu words; a node needs at least 2", n_words);
-    struct Item { uint32_t word, rec, depth; };
-    std::vector<Item> todo;
+    struct Item { uint32_t word, depth; };
+    std::vector<Item> items;        // items[i] describes out[i]; processed in order = breadth-first
     const size_t max_records = n_words;   // a tree cannot hold more nodes than words
-    auto add = [&](uint32_t word, const float lo[3], const float hi[3]) -> uint32_t {
+    auto add = [&](uint32_t word, uint32_t depth, const float lo[3], const float hi[3]) {
         RtNodeRec r{};
-        for (int k = 0; k < 8; k++) r.child[k] = RT_NO_CHILD;
-        for (int k = 0; k < 3; k++) { r.lo[k] = lo[k]; r.hi[k] = hi[k]; }
-        r.info = word;   // temporarily the word offset
+        for (int k = 0; k < 3; k++) { r.lo[k] = lo[k]; r.hi[k] = hi[k]; r.mid[k] = (hi[k] + lo[k]) / 2.0f; }   // frag:487
         out.push_back(r);
-        return (uint32_t)(out.size() - 1);
+        items.push_back({word, depth});
     };
-    todo.push_back({0u, add(0u, lo0, hi0), 0u});
-    while (!todo.empty()) {
-        const Item it = todo.back();
-        todo.pop_back();
+    add(0u, 0u, lo0, hi0);
+    for (size_t i = 0; i < out.size(); i++) {
+        const Item it = items[i];
         if ((size_t)it.word + 2 > n_words) return fail(RT_ESCENE, "node at word %u runs past the node buffer (%zu words)", it.word, n_words);
         const uint32_t info = words[it.word], tri_start = words[it.word + 1];
         const uint32_t child_count = info & 0xFu, mask = (info >> 8) & 0xFFu, tri_count = info >> 16;
@@ -99,30 +108,46 @@ int flatten_nodes(const uint32_t *words, size_t n_words, size_t n_ref, const flo
         if ((size_t)it.word + 2 + child_count > n_words) return fail(RT_ESCENE, "node at word %u: child pointers run past the node buffer", it.word);
         if ((size_t)tri_start + tri_count > n_ref) return fail(RT_ESCENE, "node at word %u: triangle range [%u,%u) exceeds %zu references", it.word, tri_start, tri_start + tri_count, n_ref);
         if (it.depth > max_depth) max_depth = it.depth;
-        RtNodeRec &r = out[it.rec];
-        float lo[3], hi[3], mid[3];
-        for (int k = 0; k < 3; k++) { lo[k] = r.lo[k]; hi[k] = r.hi[k]; mid[k] = (hi[k] + lo[k]) / 2.0f; }   // frag:487
-        r.info = info;
-        r.tri_start = tri_start;
         if (child_count && it.depth + 1 > RT_MAX_TREE_DEPTH) return fail(RT_ESCENE, "octree deeper than %u levels (or cyclic)", RT_MAX_TREE_DEPTH);
+        if (out.size() + child_count > max_records) return fail(RT_ESCENE, "node buffer describes more than %zu nodes (shared or cyclic children)", max_records);
+        float lo[3], hi[3], mid[3];
+        for (int k = 0; k < 3; k++) { lo[k] = out[i].lo[k]; hi[k] = out[i].hi[k]; mid[k] = out[i].mid[k]; }
+        out[i].info = info;
+        out[i].tri_start = tri_start;
+        out[i].first_child = (uint32_t)out.size();
         uint32_t ci = 0;
-        uint32_t child_rec[8];
-        for (int i = 0; i < 8; i++) {
-            if (!(mask & (1u << i))) continue;
+        for (int o = 0; o < 8; o++) {
+            if (!(mask & (1u << o))) continue;
             const uint32_t cw = words[it.word + 2 + ci++];
             float clo[3], chi[3];
             for (int k = 0; k < 3; k++) {   // frag:491-500
-                const bool upper = (i >> k) & 1;
+                const bool upper = (o >> k) & 1;
                 clo[k] = upper ? mid[k] : lo[k];
                 chi[k] = upper ? hi[k] : mid[k];
             }
-            if (out.size() >= max_records) return fail(RT_ESCENE, "node buffer describes more than %zu nodes (shared or cyclic children)", max_records);
-            child_rec[i] = add(cw, clo, chi);
-            todo.push_back({cw, child_rec[i], it.depth + 1});
+            add(cw, it.depth + 1, clo, chi);
         }
-        RtNodeRec &r2 = out[it.rec];   // `out` may have been reallocated by add()
-        for (int i = 0; i < 8; i++) if (mask & (1u << i)) r2.child[i] = child_rec[i];
     }
+    if (out.size() > RT_MAX_NODE_RECORDS) return fail(RT_ELIMIT, "octree has %zu nodes; at most %u are supported", out.size(), RT_MAX_NODE_RECORDS);
+    return RT_OK;
+}
+
+// One allocation carved into the workspace planes (256-byte aligned pieces).
+int ensure_workspace(rt_scene::Sub *s, size_t slots, size_t ranges) {
+    if (s->slots >= slots && s->block) return RT_OK;
+    if (s->block) { (void)hipFree(s->block); s->block = nullptr; s->slots = 0; }
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t f4 = al(slots * 16), u1 = al(slots * 4);
+    const size_t rg = al(ranges * 4);
+    const size_t total = 6 * f4 + 4 * u1 + 2 * rg + al(8 * 4) + al(96 * 16);
+    HIP_TRY(hipMalloc(&s->block, total));
+    char *p = (char *)s->block;
+    auto take = [&](size_t b) { char *q = p; p += b; return q; };
+    for (int k = 0; k < 2; k++) { s->ws.pos_seed[k] = (float4 *)take(f4); s->ws.dir_pix[k] = (float4 *)take(f4); s->ws.color[k] = (float4 *)take(f4); }
+    s->ws.t = (float *)take(u1); s->ws.sphere = (uint32_t *)take(u1); s->ws.tri = (uint32_t *)take(u1); s->ws.qt = (uint32_t *)take(u1);
+    s->ws.live[0] = (uint32_t *)take(rg); s->ws.live[1] = (uint32_t *)take(rg);
+    s->ws.ctr = (uint32_t *)take(al(8 * 4)); s->ws.prim = (float4 *)take(al(96 * 16));
+    s->slots = slots;
     return RT_OK;
 }
 
@@ -238,6 +263,20 @@ int rt_skybox_set(rt_scene *s, const uint8_t *const faces[6], int w, int h) {
     return RT_OK;
 }
 
+int rt_scene_set_pipeline(rt_scene *s, int pipeline) {
+    if (!s) return fail(RT_EINVAL, "scene is null");
+    if (pipeline != RT_PIPELINE_MEGAKERNEL && pipeline != RT_PIPELINE_WAVEFRONT) return fail(RT_EINVAL, "unknown pipeline %d", pipeline);
+    s->pipeline = pipeline;
+    return RT_OK;
+}
+
+int rt_scene_set_subframes(rt_scene *s, int n) {
+    if (!s) return fail(RT_EINVAL, "scene is null");
+    if (n < 1 || n > RT_MAX_SUBFRAMES) return fail(RT_EINVAL, "subframes must be in [1,%d]", RT_MAX_SUBFRAMES);
+    s->subframes = n;
+    return RT_OK;
+}
+
 int rt_scene_set_counting(rt_scene *s, int enabled) {
     if (!s) return fail(RT_EINVAL, "scene is null");
     s->counting = enabled != 0;
@@ -272,6 +311,7 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
     if (t->memory != RT_MEM_HOST && t->memory != RT_MEM_DEVICE) return fail(RT_EINVAL, "target memory kind %d unknown", t->memory);
     if ((f->ndc_x == nullptr) != (f->ndc_y == nullptr)) return fail(RT_EINVAL, "ndc_x and ndc_y must be given together");
     if (t->memory == RT_MEM_HOST && !t->sync) return fail(RT_EINVAL, "host-memory targets require sync = 1");
+    if ((unsigned long long)f->width * f->height >= 0xFFFFFFFFull) return fail(RT_ELIMIT, "frame has too many pixels");
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
     hipStream_t st = (hipStream_t)f->stream;
@@ -286,13 +326,54 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
     L.counters = s->counting ? s->d_counters : nullptr;
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
 
+    L.sub_parts = 1; L.sub_part = 0;
+    const bool wavefront = s->pipeline == RT_PIPELINE_WAVEFRONT && f->u.max_recursion_limit >= 1 && L.n_local_rows > 0;
+    // number of sub-frames: every one should still fill the machine (>= 64 strips of 16 rows x width)
+    uint32_t K = 1;
+    if (wavefront) {
+        const uint32_t strips = L.n_local_rows / f->band_rows;
+        K = (uint32_t)s->subframes;
+        while (K > 1 && (size_t)(strips / K) * f->band_rows * f->width < ((size_t)1 << 19)) K--;
+        for (uint32_t j = 0; j < K; j++) {
+            rt_frame fj = *f;
+            fj.band_parts = f->band_parts * K; fj.band_part = j * f->band_parts + f->band_part;
+            const uint32_t rows = band_rows_of(&fj);
+            int wrc = ensure_workspace(&s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
+            if (wrc != RT_OK) return wrc;
+            if (K > 1 && !s->sub[j].stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&s->sub[j].stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&s->sub[j].done, hipEventDisableTiming));
+            }
+        }
+        if (K > 1 && !s->fork_ev) HIP_TRY(hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
+    }
+    // Enqueues the frame: the single-kernel pipeline, or K sub-frame chains forked from / joined to the caller's stream.
+    auto launch_all = [&](const RtLaunch &L0, const char **kerr) -> int {
+        if (!wavefront) return rt_launch_render(s->d, L0, nullptr, st, kerr);
+        if (K == 1) return rt_launch_render(s->d, L0, &s->sub[0].ws, st, kerr);
+        if (hipEventRecord(s->fork_ev, st) != hipSuccess) return 1;
+        for (uint32_t j = 0; j < K; j++) {
+            RtLaunch Lj = L0;
+            rt_frame fj = *f;
+            fj.band_parts = f->band_parts * K; fj.band_part = j * f->band_parts + f->band_part;
+            Lj.band_parts = fj.band_parts; Lj.band_part = fj.band_part; Lj.n_local_rows = band_rows_of(&fj);
+            Lj.sub_parts = K; Lj.sub_part = j;
+            if (Lj.n_local_rows == 0) continue;
+            if (hipStreamWaitEvent(s->sub[j].stream, s->fork_ev, 0) != hipSuccess) return 1;
+            int rc = rt_launch_render(s->d, Lj, &s->sub[j].ws, s->sub[j].stream, kerr);
+            if (rc != 0) return rc;
+            if (hipEventRecord(s->sub[j].done, s->sub[j].stream) != hipSuccess) return 1;
+            if (hipStreamWaitEvent(st, s->sub[j].done, 0) != hipSuccess) return 1;
+        }
+        return 0;
+    };
     const size_t px = (size_t)f->width * f->height;                                            // ndc planes
     const size_t tpx = f->compact_rows ? (size_t)f->width * L.n_local_rows : px;              // target planes
     const char *kerr = nullptr;
     if (t->memory == RT_MEM_DEVICE) {
         L.ndc_x = f->ndc_x; L.ndc_y = f->ndc_y;
         L.color = t->color; L.depth = t->depth; L.hit_kind = t->hit_kind; L.hit_slot = t->hit_slot; L.hit_t = t->hit_t; L.n_rays = t->n_rays;
-        if (rt_launch_render(s->d, L, st, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
+        if (launch_all(L, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
         if (t->sync) HIP_TRY(hipStreamSynchronize(st));
         return RT_OK;
     }
@@ -316,7 +397,7 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
     L.color = (float *)s->s_color;
     L.depth = t->depth ? (float *)s->s_depth : nullptr; L.hit_kind = t->hit_kind ? (uint32_t *)s->s_kind : nullptr;
     L.hit_slot = t->hit_slot ? (uint32_t *)s->s_slot : nullptr; L.hit_t = t->hit_t ? (float *)s->s_t : nullptr; L.n_rays = t->n_rays ? (uint32_t *)s->s_nrays : nullptr;
-    if (rt_launch_render(s->d, L, st, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
+    if (launch_all(L, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
     HIP_TRY(hipMemcpyAsync(t->color, s->s_color, tpx * 16, hipMemcpyDeviceToHost, st));
     for (Plane &p : planes) if (p.host) HIP_TRY(hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -329,6 +410,12 @@ int rt_scene_destroy(rt_scene *s) {
     void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_sky, s->d_counters};
     for (void *q : p) if (q) (void)hipFree(q);
     free_staging(s);
+    for (rt_scene::Sub &sb : s->sub) {
+        if (sb.stream) { (void)hipStreamSynchronize(sb.stream); (void)hipStreamDestroy(sb.stream); }
+        if (sb.done) (void)hipEventDestroy(sb.done);
+        if (sb.block) (void)hipFree(sb.block);
+    }
+    if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
     delete s;
     return RT_OK;
 }

@@ -2,21 +2,29 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <hip/hip_runtime_api.h>
 #include "../../include/rt_hotpath.h"
 
 // One octree node as the device sees it: a single 64-byte line holding everything a visit needs -- header,
-// triangle range, the eight child slots (indexed by octant, RT_NO_CHILD where the reference's child mask has no
-// bit) and the node's own box, from which child boxes are derived by midpoint split exactly as the reference
-// shader does (ray_tracer.frag:487-500).  Built from the reference node words (Octree.cpp:44-75) by rt_scene_create.
+// triangle range, the record index of its first child and the node's own box with its midpoint, from which child
+// boxes are derived by midpoint split exactly as the reference shader does (ray_tracer.frag:487-500; the midpoint
+// (max+min)/2 is computed on the host with the same two IEEE operations).  Records are numbered breadth-first and
+// the existing children of a node are consecutive, in ascending octant order: the child in octant o is record
+// first_child + popcount(child_mask & ((1 << o) - 1)).  Built from the reference node words (Octree.cpp:44-75) by
+// rt_scene_create.
 struct alignas(64) RtNodeRec {
     uint32_t info;        // tri_count << 16 | child_mask << 8 | child_count  (reference word 0)
     uint32_t tri_start;   // reference word 1
-    uint32_t child[8];    // record index of the child in octant i
+    uint32_t first_child; // record index of the first existing child (undefined when child_count == 0)
+    uint32_t reserved;
     float lo[3];
+    float mid[3];
     float hi[3];
+    uint32_t pad[3];
 };
 static_assert(sizeof(RtNodeRec) == 64, "node record must be one 64-byte line");
-#define RT_NO_CHILD 0xFFFFFFFFu
+#define RT_MAX_SUBFRAMES 8
+#define RT_MAX_NODE_RECORDS (1u << 24)   // a traversal stack entry packs a record index into 24 bits
 
 // One triangle reference prepared for Moeller-Trumbore: first vertex and the two edges, computed on the host with
 // the same IEEE subtractions the shader performs per test (frag:256-257), so a test needs three 16-byte loads
@@ -46,11 +54,30 @@ struct RtLaunch {
     uint32_t width, height, accum_index, blend;
     uint32_t band_rows, band_parts, band_part, n_local_rows;
     uint32_t compact_rows;
+    uint32_t sub_parts, sub_part;   // this launch renders sub-frame sub_part of sub_parts of the caller's band (1, 0: all of it)
     const float *ndc_x, *ndc_y;
     float *color, *depth, *hit_t;
     uint32_t *hit_kind, *hit_slot, *n_rays;
     unsigned long long *counters;   // 8 x u64 or null
 };
 
+// Device workspace of the per-depth wavefront pipeline.  Path segments of one depth are addressed by slot; the
+// two copies of the ray planes alternate between "this depth" (index depth & 1) and "next depth".
+struct RtWorkspace {
+    float4 *pos_seed[2];   // ray origin xyz, RNG seed base
+    float4 *dir_pix[2];    // ray direction xyz, target-plane pixel index (uint bits; 0xFFFFFFFF = no pixel)
+    float4 *color[2];      // path throughput rgb
+    float *t;              // closest distance found so far in this segment
+    uint32_t *sphere;      // index of the closest sphere
+    uint32_t *tri;         // closest triangle slot | 0x80000000 when a triangle is the closest hit so far
+    uint32_t *qt;          // traversal queue: slots of the segments that enter the octree
+    uint32_t *live[2];     // per slot range: number of live segments at this / the next depth
+    uint32_t *ctr;         // 8 queue counters
+    float4 *prim;          // per-frame (oc.xyz, c) of the 84 spheres for rays starting at the camera
+};
+
 // rt_kernels.hip
-int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, void *stream, const char **err);
+size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
+size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
+// workspace == nullptr: single-kernel pipeline; otherwise the per-depth wavefront pipeline.
+int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, void *stream, const char **err);

@@ -190,6 +190,7 @@ __constant__ float4 c_spheres[NUM_SPHERES] = {
     {0.0f, 2.0f, 0.0f, 1.0f}, {-4.0f, 2.0f, 0.0f, 1.0f}, {4.0f, 2.0f, 0.0f, 1.0f},
 };
 
+
 // ------------------------------------------------------------------------------------------------
 // intersection
 // ------------------------------------------------------------------------------------------------
@@ -205,31 +206,62 @@ DEVI bool ray_aabb(const Ray &r, f3 lo, f3 hi, float closest) {
     const float tmax = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
     return tmax > 0.0f && tmin < tmax && tmin < closest;
 }
+DEVI bool root_box_test(const RtDeviceScene &S, const Ray &r, float closest) {
+    if (S.n_nodes == 0) return false;
+    return ray_aabb(r, F3(S.bounds_min[0], S.bounds_min[1], S.bounds_min[2]), F3(S.bounds_max[0], S.bounds_max[1], S.bounds_max[2]), closest);
+}
 
-// frag:233-252 over frag:439-445.  Each sphere's candidate t does not depend on the running closest distance
-// except through the final filter, so the loop keeps the reference's sequential accept rule unchanged.
-DEVI void intersect_spheres(const Ray &r, float &closest, uint32_t &closest_i) {
-#pragma unroll 4
+// frag:233-252 applied to one sphere given oc = ray.pos - centre and c = dot(oc,oc) - r*r.  A sphere's candidate t
+// does not depend on the running closest distance except through the final accept filter, so the reference's
+// sequential rule (first index wins ties, frag:439-445) is kept by testing in index order.
+DEVI void sphere_accept(float b, float c, uint32_t i, float &closest, uint32_t &closest_i) {
+    const float disc = b * b - c;
+    if (disc < 0.0f) return;
+    const float sq = sqrt_ieee(disc);
+    const float t1 = -b - sq, t2 = -b + sq;
+    const float t = t1 < 0.0f ? t2 : t1;
+    if (t < closest && t > 0.0f) { closest = t; closest_i = i; }
+}
+// The 84 sphere records are read from a workgroup-shared LDS copy (every lane reads the same address: a broadcast),
+// whose loads the compiler can keep in flight ahead of the arithmetic; scalar loads from constant memory cannot be
+// waited for individually and stalled every group of spheres.
+DEVI void stage_sphere_table(float4 *lds_tab, const float4 *src) {
+    if (threadIdx.x < NUM_SPHERES) lds_tab[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+}
+// Generic origin: lds_tab holds (centre.xyz, radius).
+DEVI void intersect_spheres(const float4 *lds_tab, const Ray &r, float &closest, uint32_t &closest_i) {
+#pragma unroll 6
     for (uint32_t i = 0; i < NUM_SPHERES; i++) {
-        const float4 s = c_spheres[i];
+        const float4 s = lds_tab[i];
         const f3 oc = r.pos - F3(s.x, s.y, s.z);
         const float b = dot3(oc, r.dir);
         const float c = dot3(oc, oc) - s.w * s.w;
-        const float disc = b * b - c;
-        if (disc < 0.0f) continue;
-        const float sq = sqrt_ieee(disc);
-        const float t1 = -b - sq, t2 = -b + sq;
-        const float t = t1 < 0.0f ? t2 : t1;
-        if (t < closest && t > 0.0f) { closest = t; closest_i = i; }
+        sphere_accept(b, c, i, closest, closest_i);
+    }
+}
+// Primary rays share their origin, so oc and c are per-frame constants of each sphere: lds_tab holds (oc.xyz, c)
+// computed once with the very same operations.
+DEVI void intersect_spheres_primary(const float4 *lds_tab, f3 dir, float &closest, uint32_t &closest_i) {
+#pragma unroll 6
+    for (uint32_t i = 0; i < NUM_SPHERES; i++) {
+        const float4 s = lds_tab[i];
+        const float b = dot3(F3(s.x, s.y, s.z), dir);
+        sphere_accept(b, s.w, i, closest, closest_i);
     }
 }
 
-// frag:255-281 on a prepared triangle record
-DEVI float ray_triangle(const Ray &r, const RtTriRec *tr) {
-    const float4 q0 = *reinterpret_cast<const float4 *>(tr);
-    const float4 q1 = *(reinterpret_cast<const float4 *>(tr) + 1);
-    const float q2 = tr->e2z;
-    const f3 v1 = F3(q0.x, q0.y, q0.z), e1 = F3(q0.w, q1.x, q1.y), e2 = F3(q1.z, q1.w, q2);
+// frag:255-281 on a prepared triangle record (first vertex and the two edges)
+struct TriData { float4 q0, q1; float e2z; };
+DEVI TriData load_triangle(const RtTriRec *tr) {
+    TriData d;
+    d.q0 = *reinterpret_cast<const float4 *>(tr);
+    d.q1 = *(reinterpret_cast<const float4 *>(tr) + 1);
+    d.e2z = tr->e2z;
+    return d;
+}
+DEVI float ray_triangle(const Ray &r, const TriData &d) {
+    const f3 v1 = F3(d.q0.x, d.q0.y, d.q0.z), e1 = F3(d.q0.w, d.q1.x, d.q1.y), e2 = F3(d.q1.z, d.q1.w, d.e2z);
     const f3 pvec = cross3(r.dir, e2);
     const float det = dot3(e1, pvec);
     if (__builtin_fabsf(det) < 0.000000000000001f) return -1.0f;
@@ -243,43 +275,92 @@ DEVI float ray_triangle(const Ray &r, const RtTriRec *tr) {
     return dot3(e2, qvec) * inv_det;
 }
 
-// frag:455-514: depth-first, children pushed in ascending octant order and popped from the top, pruned at push
-// time against the closest distance known then -- the visit order decides which duplicate of a triangle wins
-// ties, so it is kept exactly.
-template <int STACK, bool COUNT>
-DEVI void traverse_octree(const RtDeviceScene &S, const Ray &r, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
-    if (S.n_nodes == 0) return;
-    if (!ray_aabb(r, F3(S.bounds_min[0], S.bounds_min[1], S.bounds_min[2]), F3(S.bounds_max[0], S.bounds_max[1], S.bounds_max[2]), closest)) return;
-    if (COUNT) cn.entered++;
-    uint32_t stack[STACK];
-    int sp = 0;
-    stack[sp++] = 0;
-    while (sp != 0) {
-        const uint32_t ni = stack[--sp];
-        const uint4 *rec = reinterpret_cast<const uint4 *>(S.nodes + ni);
-        const uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
-        const uint32_t info = w0.x, tri_start = w0.y;
-        const uint32_t tri_count = info >> 16;
-        if (COUNT) { cn.pops++; cn.tri_tests += tri_count; }
-        for (uint32_t i = 0; i < tri_count; i++) {
-            const float t = ray_triangle(r, S.tris + (tri_start + i));
-            if (t >= 0.0f && t < closest) { closest = t; closest_tri = tri_start + i; tri_hit = true; }
-        }
-        const uint32_t mask = (info >> 8) & 0xffu;
-        if (mask == 0) continue;
-        const uint32_t child[8] = {w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y};
-        const f3 lo = F3(u2f(w2.z), u2f(w2.w), u2f(w3.x)), hi = F3(u2f(w3.y), u2f(w3.z), u2f(w3.w));
-        const f3 mid = F3((hi.x + lo.x) / 2.0f, (hi.y + lo.y) / 2.0f, (hi.z + lo.z) / 2.0f);
+// Depth-first traversal state (frag:431-433,455-514).  The reference keeps a LIFO of (box, node) pairs: a visit
+// pushes the children whose boxes pass the slab test in ascending octant order and the next visit pops the top, so the
+// passing children of a node are visited in descending octant order, each with its whole subtree, before the
+// node's siblings.  That order is reproduced with ONE entry per tree level instead of one per pending node: an entry
+// holds the record index of the node's first child and the set of passing children still to visit, as a bitmask
+// over their ranks among the existing children (entry = first_child | rank_mask << 24).  The slab tests happen, as
+// in the reference, when the parent is visited -- against the closest distance known at that moment -- and are
+// never repeated.  The stack is a column of LDS: entry k of thread t lives at lds[k * 256 + t] (no bank conflicts
+// whatever the lanes' depths), and it can never hold more than one entry per tree level.
+struct LevelStack {
+    uint32_t *col;   // &lds[threadIdx.x]
+    int sp;
+    DEVI void reset_to_root() { col[0] = 0u | (1u << 24); sp = 1; }   // the root is rank 0 of a virtual level
+    DEVI bool empty() const { return sp == 0; }
+    DEVI uint32_t pop_node() {
+        const uint32_t e = col[(sp - 1) * 256];
+        const uint32_t mask = e >> 24;
+        const uint32_t r = 31u - (uint32_t)__clz((int)mask);      // highest pending rank = highest octant
+        const uint32_t rest = mask & ~(1u << r);
+        if (rest) col[(sp - 1) * 256] = (e & 0x00FFFFFFu) | (rest << 24);
+        else sp--;
+        return (e & 0x00FFFFFFu) + r;
+    }
+    DEVI void push_level(uint32_t first_child, uint32_t rank_mask) { col[sp * 256] = first_child | (rank_mask << 24); sp++; }
+};
+
+// Slab tests of the up-to-eight child boxes of a node (frag:489-513).  The eight boxes only use three plane
+// positions per axis (lo, mid, hi), so the reference's per-child (bound - origin) * inverse_direction products and
+// their min/max are computed once per plane pair and shared: every value is produced by the same operation on the same
+// operands as in the reference, only not recomputed.  Returns the passing children as a bitmask over their RANKS among
+// the existing children (child_mask), in ascending octant order.
+DEVI uint32_t child_pass_ranks(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest) {
+    const f3 tl = (lo - r.pos) * r.inv, tm = (mid - r.pos) * r.inv, th = (hi - r.pos) * r.inv;
+    // lower half of an axis: box [lo, mid] -> t1 = tl, t2 = tm; upper half: box [mid, hi] -> t1 = tm, t2 = th
+    const f3 near0 = F3(fminf(tl.x, tm.x), fminf(tl.y, tm.y), fminf(tl.z, tm.z)), far0 = F3(fmaxf(tl.x, tm.x), fmaxf(tl.y, tm.y), fmaxf(tl.z, tm.z));
+    const f3 near1 = F3(fminf(tm.x, th.x), fminf(tm.y, th.y), fminf(tm.z, th.z)), far1 = F3(fmaxf(tm.x, th.x), fmaxf(tm.y, th.y), fmaxf(tm.z, th.z));
+    uint32_t oct_pass = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (mask & (1u << i)) {
-                const f3 clo = F3((i & 1) ? mid.x : lo.x, (i & 2) ? mid.y : lo.y, (i & 4) ? mid.z : lo.z);
-                const f3 chi = F3((i & 1) ? hi.x : mid.x, (i & 2) ? hi.y : mid.y, (i & 4) ? hi.z : mid.z);
-                if (COUNT) cn.box_tests++;
-                if (ray_aabb(r, clo, chi, closest) && sp < STACK) stack[sp++] = child[i];
+    for (int i = 0; i < 8; i++) {
+        const float nx = (i & 1) ? near1.x : near0.x, ny = (i & 2) ? near1.y : near0.y, nz = (i & 4) ? near1.z : near0.z;
+        const float fx = (i & 1) ? far1.x : far0.x, fy = (i & 2) ? far1.y : far0.y, fz = (i & 4) ? far1.z : far0.z;
+        const float tmin = fmaxf(fmaxf(nx, ny), nz), tmax = fminf(fminf(fx, fy), fz);
+        if (tmax > 0.0f && tmin < tmax && tmin < closest) oct_pass |= 1u << i;
+    }
+    oct_pass &= child_mask;
+    // octant bits -> rank bits: rank of octant o = popcount(child_mask below o)
+    uint32_t ranks = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (oct_pass & (1u << i)) ranks |= 1u << __popc(child_mask & ((1u << i) - 1u));
+    return ranks;
+}
+
+struct NodeData { uint32_t tri_start, tri_count, child_mask, first_child; f3 lo, mid, hi; };
+DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
+    const uint4 *rec = reinterpret_cast<const uint4 *>(S.nodes + ni);
+    const uint4 w0 = rec[0];
+    const float4 w1 = reinterpret_cast<const float4 *>(rec)[1], w2 = reinterpret_cast<const float4 *>(rec)[2];
+    const float hiz = reinterpret_cast<const float *>(rec)[12];
+    NodeData n;
+    n.tri_start = w0.y; n.tri_count = w0.x >> 16; n.child_mask = (w0.x >> 8) & 0xffu; n.first_child = w0.z;
+    n.lo = F3(w1.x, w1.y, w1.z); n.mid = F3(w1.w, w2.x, w2.y); n.hi = F3(w2.z, w2.w, hiz);
+    return n;
+}
+
+// One visit (frag:456-513) by a single lane: test the node's triangles in order, then the boxes of its children.
+template <bool COUNT>
+DEVI void visit_node(const RtDeviceScene &S, const Ray &r, LevelStack &st, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
+    const NodeData n = load_node(S, st.pop_node());
+    if (COUNT) { cn.pops++; cn.tri_tests += n.tri_count; cn.box_tests += __popc(n.child_mask); }
+    // triangle records are fetched four at a time so that their memory latencies overlap; they are tested in order
+    for (uint32_t i0 = 0; i0 < n.tri_count; i0 += 4) {
+        TriData td[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) td[k] = load_triangle(S.tris + (n.tri_start + min(i0 + k, n.tri_count - 1u)));
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            if (i0 + k < n.tri_count) {
+                const float t = ray_triangle(r, td[k]);
+                if (t >= 0.0f && t < closest) { closest = t; closest_tri = n.tri_start + i0 + k; tri_hit = true; }
             }
         }
     }
+    if (n.child_mask == 0) return;
+    const uint32_t pass = child_pass_ranks(r, n.lo, n.mid, n.hi, n.child_mask, closest);
+    if (pass) st.push_level(n.first_child, pass);
 }
 
 DEVI float sign1(float y) { return y > 0.0f ? 1.0f : (y < 0.0f ? -1.0f : 0.0f); }
@@ -348,16 +429,11 @@ DEVI f3 barycentric(f3 p, f3 a, f3 b, f3 c) {
     return F3(u, v, w);
 }
 
-// frag:427-563
-template <int STACK, bool COUNT>
-DEVI Hit find_intersection(const RtDeviceScene &S, const rt_uniforms &U, const Ray &r, PrimaryTap *tap, Counters &cn) {
-    float closest = __builtin_inff();
-    uint32_t closest_i = 0, closest_tri = 0;
-    bool tri_hit = false, cyl_hit = false;
-    if (COUNT) cn.rays++;
-    intersect_spheres(r, closest, closest_i);
-    traverse_octree<STACK, COUNT>(S, r, closest, closest_tri, tri_hit, cn);
-
+// Everything of FindIntersection after the octree loop (frag:517-562): cylinder, portals, hit assembly.
+template <bool COUNT>
+DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const Ray &r, float closest, uint32_t closest_i, uint32_t closest_tri, bool tri_hit,
+                             PrimaryTap *tap, Counters &cn) {
+    bool cyl_hit = false;
     f3 cyl_n = F3(0.0f, 0.0f, 0.0f);
     const float cyl_t = ray_cylinder(r, closest, cyl_n);
     if (!is_inf(cyl_t)) { cyl_hit = true; closest = cyl_t; }
@@ -452,7 +528,7 @@ DEVI f3 sample_sky(const RtDeviceScene &S, f3 d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// path loop (frag:566-687)
+// ray generation, scattering, tonemap (frag:566-687)
 // ------------------------------------------------------------------------------------------------
 DEVI f3 mat_dir(const float *M, f3 v) {     // (M * vec4(v, 0)).xyz
     return F3((M[0] * v.x + M[4] * v.y) + M[8] * v.z, (M[1] * v.x + M[5] * v.y) + M[9] * v.z, (M[2] * v.x + M[6] * v.y) + M[10] * v.z);
@@ -463,189 +539,531 @@ DEVI f3 mat_point(const float *M, f3 v) {   // (M * vec4(v, 1)).xyz
 DEVI float nonlinear_depth(float d, float zn, float zf) { return div_ieee(zn * zf - d * zf, d * (zn - zf)); }   // frag:352-354
 DEVI float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
-struct PixelOut { f3 color; float depth; PrimaryTap tap; uint32_t nrays; };
-
-template <int STACK, bool COUNT>
-DEVI void shade_pixel(const RtDeviceScene &S, const rt_uniforms &U, float ndc_x, float ndc_y, PixelOut &o, Counters &cn) {
+// frag:674-684.  Returns the primary ray direction and the re-based seed handed to the path loop.
+DEVI void generate_ray(const rt_uniforms &U, float ndc_x, float ndc_y, f3 &dir, float &seed_base) {
     const float *M = U.inv_view_proj_mat;
     const f3 cam = F3(U.camera_position[0], U.camera_position[1], U.camera_position[2]);
-    // frag:676-677; evaluated ((M0*x + (-M2)) + M1*y) + M3
     float p[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) p[r] = ((M[r] * ndc_x + (-M[8 + r])) + M[4 + r] * ndc_y) + M[12 + r];
+    for (int r = 0; r < 4; r++) p[r] = ((M[r] * ndc_x + (-M[8 + r])) + M[4 + r] * ndc_y) + M[12 + r];   // frag:676 as evaluated
     const f3 pp = F3(div_ieee(p[0], p[3]), div_ieee(p[1], p[3]), div_ieee(p[2], p[3]));
-    // frag:679-680
-    const float s1 = (float)base_hash(f2u(pp.x - U.time), f2u(pp.y - U.time)) / 4294967296.0f;
+    const float s1 = (float)base_hash(f2u(pp.x - U.time), f2u(pp.y - U.time)) / 4294967296.0f;   // frag:679
     Seed seed;
-    seed.base = (float)base_hash(f2u(s1), f2u(s1)) / 4294967296.0f;
+    seed.base = (float)base_hash(f2u(s1), f2u(s1)) / 4294967296.0f;                               // frag:680
     seed.k = 0;
-    // frag:682-684
     const f3 jit = random_in_unit_sphere(seed);
-    Ray ray;
-    ray.pos = cam;
-    ray.dir = normalize3(pp - (cam + jit * U.blur_amount));
-    ray.inv = rcp3(ray.dir);
+    dir = normalize3(pp - (cam + jit * U.blur_amount));                                           // frag:682
     seed.rebase();
+    seed_base = seed.base;
+}
 
-    float depth = 1.0f;
-    f3 color = F3(1.0f, 1.0f, 1.0f);
-    o.nrays = 0;
-    o.tap.kind = RT_HIT_MISS; o.tap.slot = 0; o.tap.t = __builtin_inff();
-    const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
-    const f3 pd1 = F3(U.portal_direction_1[0], U.portal_direction_1[1], U.portal_direction_1[2]);
-    const f3 pp2 = F3(U.portal_position_2[0], U.portal_position_2[1], U.portal_position_2[2]);
-    const f3 pd2 = F3(U.portal_direction_2[0], U.portal_direction_2[1], U.portal_direction_2[2]);
+// First-segment depth (frag:575-581)
+DEVI float first_hit_depth(const rt_uniforms &U, const Hit &h, const Ray &ray) {
+    if (h.has_hit) return clamp01(nonlinear_depth(length3(h.position - ray.pos), U.z_near, U.z_far));
+    return clamp01(nonlinear_depth(U.z_far, U.z_near, U.z_far));
+}
 
-    for (uint32_t i = 0; i < U.max_recursion_limit; i++) {
-        const Hit h = find_intersection<STACK, COUNT>(S, U, ray, i == 0 ? &o.tap : nullptr, cn);
-        o.nrays++;
-        if (i == 0) {
-            if (h.has_hit) depth = clamp01(nonlinear_depth(length3(h.position - ray.pos), U.z_near, U.z_far));
-            else depth = clamp01(nonlinear_depth(U.z_far, U.z_near, U.z_far));
-        }
-        if (!h.has_hit) {
-            color = color * sample_sky(S, ray.dir);
-            break;
-        }
-        if (h.portal_id != 0) {
-            const bool one = h.portal_id == 1;
-            const f3 pd = one ? pd1 : pd2, psrc = one ? pp1 : pp2, pdst = one ? pp2 : pp1;
-            const float *PM = one ? U.portal_1_to_2 : U.portal_2_to_1;
-            color = color * (dot3(ray.dir, pd) < 0.0f ? 0.5f : 0.05f);
-            ray.pos = mat_point(PM, h.position - psrc) + pdst;
-            ray.dir = normalize3(mat_dir(PM, ray.dir));
-            ray.pos = ray.pos + ray.dir * 0.001f;
-        } else {
-            const Material m = c_materials[h.material_id];
-            const f3 mcol = F3(m.r, m.g, m.b);
-            if (m.type == LAMBERTIAN) {
-                const float F = fresnel_schlick_roughness(fmaxf(-dot3(ray.dir, h.normal), 0.0f), 0.04f, m.roughness);
-                ray.pos = h.position + h.normal * 0.001f;
-                if (hash1(seed) > F) {
-                    color = color * mcol;
-                    ray.dir = random_cos_weighted_hemisphere_direction(h.normal, seed);
-                } else {
-                    ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
-                }
-            } else if (m.type == METAL) {
-                ray.pos = h.position + h.normal * 0.001f;
-                ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
+// One iteration of the path loop after the intersection (frag:583-659) for a hit: updates ray, colour and seed.
+DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed &seed) {
+    if (h.portal_id != 0) {
+        const bool one = h.portal_id == 1;
+        const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
+        const f3 pd1 = F3(U.portal_direction_1[0], U.portal_direction_1[1], U.portal_direction_1[2]);
+        const f3 pp2 = F3(U.portal_position_2[0], U.portal_position_2[1], U.portal_position_2[2]);
+        const f3 pd2 = F3(U.portal_direction_2[0], U.portal_direction_2[1], U.portal_direction_2[2]);
+        const f3 pd = one ? pd1 : pd2, psrc = one ? pp1 : pp2, pdst = one ? pp2 : pp1;
+        const float *PM = one ? U.portal_1_to_2 : U.portal_2_to_1;
+        color = color * (dot3(ray.dir, pd) < 0.0f ? 0.5f : 0.05f);
+        ray.pos = mat_point(PM, h.position - psrc) + pdst;
+        ray.dir = normalize3(mat_dir(PM, ray.dir));
+        ray.pos = ray.pos + ray.dir * 0.001f;
+    } else {
+        const Material m = c_materials[h.material_id];
+        const f3 mcol = F3(m.r, m.g, m.b);
+        if (m.type == LAMBERTIAN) {
+            const float F = fresnel_schlick_roughness(fmaxf(-dot3(ray.dir, h.normal), 0.0f), 0.04f, m.roughness);
+            ray.pos = h.position + h.normal * 0.001f;
+            if (hash1(seed) > F) {
                 color = color * mcol;
+                ray.dir = random_cos_weighted_hemisphere_direction(h.normal, seed);
             } else {
-                float ri, cosine; f3 on;
-                const float dn = dot3(ray.dir, h.normal);
-                if (dn > 0.0f) {
-                    ri = m.refractive_index;
-                    cosine = sqrt_ieee(1.0f - ri * ri * (1.0f - dn * dn));
-                    on = -h.normal;
-                } else {
-                    ri = rcp_ieee(m.refractive_index);
-                    cosine = -dn;
-                    on = h.normal;
-                }
-                const f3 md = ray.dir + random_in_unit_sphere(seed) * m.roughness;
-                const f3 refr = normalize3(refract3(md, on, ri));
-                if (refr.x != 0.0f || refr.y != 0.0f || refr.z != 0.0f) {   // true for NaN (total internal reflection)
-                    const float rr = div_ieee(1.0f - ri, 1.0f + ri);
-                    const float F = fresnel_schlick_roughness(cosine, rr * rr, m.roughness);
-                    if (hash1(seed) > F) { ray.pos = h.position - on * 0.001f; ray.dir = refr; }
-                    else { ray.pos = h.position + on * 0.001f; ray.dir = normalize3(reflect3(md, on)); }
-                } else {
-                    ray.pos = h.position - on * 0.001f;
-                    ray.dir = normalize3(reflect3(md, on));
-                }
+                ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
+            }
+        } else if (m.type == METAL) {
+            ray.pos = h.position + h.normal * 0.001f;
+            ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
+            color = color * mcol;
+        } else {
+            float ri, cosine; f3 on;
+            const float dn = dot3(ray.dir, h.normal);
+            if (dn > 0.0f) {
+                ri = m.refractive_index;
+                cosine = sqrt_ieee(1.0f - ri * ri * (1.0f - dn * dn));
+                on = -h.normal;
+            } else {
+                ri = rcp_ieee(m.refractive_index);
+                cosine = -dn;
+                on = h.normal;
+            }
+            const f3 md = ray.dir + random_in_unit_sphere(seed) * m.roughness;
+            const f3 refr = normalize3(refract3(md, on, ri));
+            if (refr.x != 0.0f || refr.y != 0.0f || refr.z != 0.0f) {   // true for NaN (total internal reflection)
+                const float rr = div_ieee(1.0f - ri, 1.0f + ri);
+                const float F = fresnel_schlick_roughness(cosine, rr * rr, m.roughness);
+                if (hash1(seed) > F) { ray.pos = h.position - on * 0.001f; ray.dir = refr; }
+                else { ray.pos = h.position + on * 0.001f; ray.dir = normalize3(reflect3(md, on)); }
+            } else {
+                ray.pos = h.position - on * 0.001f;
+                ray.dir = normalize3(reflect3(md, on));
             }
         }
-        ray.inv = rcp3(ray.dir);
-        seed.rebase();
     }
-    // frag:667-668
+    seed.rebase();
+}
+
+// frag:667-668
+DEVI f3 tonemap(f3 color) {
     float c[3] = {color.x, color.y, color.z};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float x = fmaxf(0.0f, c[k] - 0.004f);
         c[k] = div_ieee(x * (6.2f * x + 0.5f), x * (6.2f * x + 1.7f) + 0.06f);
     }
-    o.color = F3(c[0], c[1], c[2]);
-    o.depth = depth;
+    return F3(c[0], c[1], c[2]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Frame kernel: one lane per pixel, one wave per 8x8 pixel tile, 4 waves (a 16x16 tile) per workgroup.
-// Workgroups are renumbered so that the 8 round-robin dispatch classes (blockIdx % 8, the workgroups that share an
+// Colour attachment write with the blend state of App.cpp:49,104: dst = src*(1/n) + dst*(1 - 1/n) on all four
+// channels (src alpha = 0), or a plain store when blending is off.
+DEVI void write_pixel(const RtLaunch &L, size_t pi, f3 c) {
+    float4 *dstp = reinterpret_cast<float4 *>(L.color) + pi;
+    float4 out;
+    if (L.blend) {
+        const float a = rcp_ieee((float)L.accum_index), ia = 1.0f - a;
+        const float4 dst = *dstp;
+        out.x = c.x * a + dst.x * ia; out.y = c.y * a + dst.y * ia; out.z = c.z * a + dst.z * ia; out.w = 0.0f * a + dst.w * ia;
+    } else {
+        out.x = c.x; out.y = c.y; out.z = c.z; out.w = 0.0f;
+    }
+    *dstp = out;
+}
+
+// Pixel addressing shared by both pipelines: one wave per 8x8 pixel tile, 4 waves (a 16x16 tile) per workgroup;
+// workgroups are renumbered so that the 8 round-robin dispatch classes (blockIdx % 8: the workgroups that share an
 // XCD's L2) each own a contiguous range of tiles.
-// ------------------------------------------------------------------------------------------------
-template <int STACK, bool COUNT>
-__global__ __launch_bounds__(256) void render_kernel(RtDeviceScene S, RtLaunch L) {
-    const uint32_t tiles_x = (L.width + 15u) / 16u;
-    const uint32_t tiles_y = (L.n_local_rows + 15u) / 16u;
+struct PixelId { uint32_t x, y, lr; bool active; size_t fi, pi; };
+DEVI PixelId pixel_of(const RtLaunch &L, uint32_t bid_raw, uint32_t tid) {
+    const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
     const uint32_t nwg = tiles_x * tiles_y;
-    uint32_t bid = blockIdx.x;
-    {   // bijective XCD-class remap
-        const uint32_t q = nwg / 8u, rem = nwg % 8u, cls = bid % 8u, idx = bid / 8u;
-        bid = (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;
-    }
+    const uint32_t q = nwg / 8u, rem = nwg % 8u, cls = bid_raw % 8u, idx = bid_raw / 8u;
+    const uint32_t bid = (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;   // bijective
     const uint32_t tile_x = bid % tiles_x, tile_y = bid / tiles_x;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t x = tile_x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t lr = tile_y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    // local row -> frame row: strip j of this part is global strip j*parts + part
-    const uint32_t y = ((lr / L.band_rows) * L.band_parts + L.band_part) * L.band_rows + (lr % L.band_rows);
-    const bool active = x < L.width && lr < L.n_local_rows && y < L.height;
-    Counters cn = {0, 0, 0, 0, 0, 0};
-    if (active) {
-        const size_t fi = (size_t)y * L.width + x;                                  // full-frame pixel index
-        const size_t pi = L.compact_rows ? (size_t)lr * L.width + x : fi;          // index into the target planes
-        const float nx = L.ndc_x ? L.ndc_x[fi] : div_ieee(2.0f * ((float)x + 0.5f), (float)L.width) - 1.0f;
-        const float ny = L.ndc_y ? L.ndc_y[fi] : div_ieee(2.0f * ((float)y + 0.5f), (float)L.height) - 1.0f;
-        PixelOut o;
-        shade_pixel<STACK, COUNT>(S, L.u, nx, ny, o, cn);
-        float4 *dstp = reinterpret_cast<float4 *>(L.color) + pi;
-        float4 out;
-        if (L.blend) {   // App.cpp:49,104: dst = src*(1/n) + dst*(1 - 1/n) on all four channels (src alpha = 0)
-            const float a = rcp_ieee((float)L.accum_index), ia = 1.0f - a;
-            const float4 dst = *dstp;
-            out.x = o.color.x * a + dst.x * ia; out.y = o.color.y * a + dst.y * ia; out.z = o.color.z * a + dst.z * ia; out.w = 0.0f * a + dst.w * ia;
-        } else {
-            out.x = o.color.x; out.y = o.color.y; out.z = o.color.z; out.w = 0.0f;
-        }
-        *dstp = out;
-        if (L.depth) L.depth[pi] = o.depth;
-        if (L.hit_kind) L.hit_kind[pi] = o.tap.kind;
-        if (L.hit_slot) L.hit_slot[pi] = o.tap.slot;
-        if (L.hit_t) L.hit_t[pi] = o.tap.t;
-        if (L.n_rays) L.n_rays[pi] = o.nrays;
-    }
-    if (COUNT && L.counters) {
-        atomicAdd(&L.counters[0], (unsigned long long)cn.rays);
-        atomicAdd(&L.counters[1], (unsigned long long)cn.pops);
-        atomicAdd(&L.counters[2], (unsigned long long)cn.tri_tests);
-        atomicAdd(&L.counters[3], (unsigned long long)cn.box_tests);
-        atomicAdd(&L.counters[4], (unsigned long long)cn.tri_shaded);
-        atomicAdd(&L.counters[5], (unsigned long long)cn.entered);
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    PixelId p;
+    p.x = tile_x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    p.lr = tile_y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    // local row -> frame row: strip j of this part is frame strip j*parts + part
+    p.y = ((p.lr / L.band_rows) * L.band_parts + L.band_part) * L.band_rows + (p.lr % L.band_rows);
+    p.active = p.x < L.width && p.lr < L.n_local_rows && p.y < L.height;
+    p.fi = (size_t)p.y * L.width + p.x;                                   // full-frame pixel index (NDC tables)
+    // index into the target planes; in compact mode the rows of this launch's strips are interleaved with those of
+    // the other sub-frames of the same part (sub-frame j of K owns every K-th strip of the part)
+    const uint32_t part_lr = ((p.lr / L.band_rows) * L.sub_parts + L.sub_part) * L.band_rows + (p.lr % L.band_rows);
+    p.pi = L.compact_rows ? (size_t)part_lr * L.width + p.x : p.fi;
+    return p;
+}
+DEVI void pixel_ndc(const RtLaunch &L, const PixelId &p, float &nx, float &ny) {
+    nx = L.ndc_x ? L.ndc_x[p.fi] : div_ieee(2.0f * ((float)p.x + 0.5f), (float)L.width) - 1.0f;
+    ny = L.ndc_y ? L.ndc_y[p.fi] : div_ieee(2.0f * ((float)p.y + 0.5f), (float)L.height) - 1.0f;
+}
+
+DEVI uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
+    const uint32_t v[6] = {wave_sum(cn.rays), wave_sum(cn.pops), wave_sum(cn.tri_tests), wave_sum(cn.box_tests), wave_sum(cn.tri_shaded), wave_sum(cn.entered)};
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (v[k]) atomicAdd(&ctr[k], (unsigned long long)v[k]);
     }
 }
 
-template <int STACK>
-int launch_with_stack(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid) {
-    if (L.counters) hipLaunchKernelGGL((render_kernel<STACK, true>), grid, dim3(256), 0, st, S, L);
-    else hipLaunchKernelGGL((render_kernel<STACK, false>), grid, dim3(256), 0, st, S, L);
+// ================================================================================================
+// Pipeline 1: one kernel, one lane per pixel for the whole path (kept as the simple cross-check).
+// ================================================================================================
+template <int LEVELS, bool COUNT>
+__global__ __launch_bounds__(256) void render_kernel(RtDeviceScene S, RtLaunch L) {
+    __shared__ uint32_t lds_stack[LEVELS * 256];
+    __shared__ float4 lds_sph[NUM_SPHERES];
+    stage_sphere_table(lds_sph, c_spheres);
+    LevelStack st;
+    st.col = &lds_stack[threadIdx.x];
+    st.sp = 0;
+    const PixelId p = pixel_of(L, blockIdx.x, threadIdx.x);
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    if (p.active) {
+        float nx, ny;
+        pixel_ndc(L, p, nx, ny);
+        Ray ray;
+        Seed seed;
+        seed.k = 0;
+        ray.pos = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]);
+        generate_ray(L.u, nx, ny, ray.dir, seed.base);
+        ray.inv = rcp3(ray.dir);
+        float depth = 1.0f;
+        f3 color = F3(1.0f, 1.0f, 1.0f);
+        uint32_t nrays = 0;
+        PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
+        for (uint32_t i = 0; i < L.u.max_recursion_limit; i++) {
+            float closest = __builtin_inff();
+            uint32_t closest_i = 0, closest_tri = 0;
+            bool tri_hit = false;
+            if (COUNT) cn.rays++;
+            intersect_spheres(lds_sph, ray, closest, closest_i);
+            if (root_box_test(S, ray, closest)) {
+                if (COUNT) cn.entered++;
+                st.reset_to_root();
+                while (!st.empty()) visit_node<COUNT>(S, ray, st, closest, closest_tri, tri_hit, cn);
+            }
+            const Hit h = finish_intersection<COUNT>(S, L.u, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
+            nrays++;
+            if (i == 0) depth = first_hit_depth(L.u, h, ray);
+            if (!h.has_hit) { color = color * sample_sky(S, ray.dir); break; }
+            scatter(L.u, h, ray, color, seed);
+            ray.inv = rcp3(ray.dir);
+        }
+        write_pixel(L, p.pi, tonemap(color));
+        if (L.depth) L.depth[p.pi] = depth;
+        if (L.hit_kind) L.hit_kind[p.pi] = tap.kind;
+        if (L.hit_slot) L.hit_slot[p.pi] = tap.slot;
+        if (L.hit_t) L.hit_t[p.pi] = tap.t;
+        if (L.n_rays) L.n_rays[p.pi] = nrays;
+    }
+    if (COUNT && L.counters) flush_counters(L.counters, cn);
+}
+
+// ================================================================================================
+// Pipeline 2: per-depth wavefront.  Path segments of one depth live in slot-indexed planes.  The slot space is cut
+// into ranges of RANGE slots, each owned by one workgroup for the whole frame: at depth 0 a range holds four 16x16
+// pixel tiles; the paths of a range that survive a depth are compacted to the front of the same range of the
+// next-depth planes (a workgroup-local prefix sum: no global atomics), so range b holds live[depth][b] segments.
+// For every depth:
+//   spheres_kernel   all segments, dense: (ray generation at depth 0,) the 84-sphere loop and the root box test;
+//                    the slots of segments that enter the octree are appended to the global traversal queue with
+//                    one atomic per workgroup chunk
+//   traverse_kernel  persistent waves take batches of the traversal queue; a lane that empties its stack hands its
+//                    result back and the wave refills its idle lanes together once enough of them wait
+//   shade_kernel     all segments, dense: cylinder, portals, hit assembly, scattering; finished paths are tonemapped
+//                    and blended into the target, continuing ones are compacted into the next depth's planes
+// Counters (uint32): ctr[QT_COUNT + (d&1)], ctr[QT_HEAD + (d&1)] traversal queue of depth d; ctr[ALIVE] paths that
+// continue past the depth being shaded (maintained only where the host asks for it).
+// ================================================================================================
+enum { QT_COUNT = 0, QT_HEAD = 2, ALIVE = 4 };
+#define RANGE 1024u            // slots per workgroup-owned range (4 chunks of 256)
+#ifndef REFILL_IDLE
+#define REFILL_IDLE 16         // lanes that must be waiting before a traversal wave refills them together
+#endif
+#ifndef TRAVERSE_BATCH
+#define TRAVERSE_BATCH 128u    // queue entries a traversal wave reserves with one atomic
+#endif
+#ifndef TRAVERSE_WG_PER_CU
+#define TRAVERSE_WG_PER_CU 5   // persistent traversal workgroups per CU
+#endif
+
+// Workgroup-wide exclusive prefix of a per-lane predicate over the 4 waves of a 256-thread workgroup.
+// Returns the lane's rank among the set lanes; total = number of set lanes.  Must be reached by all 256 threads.
+DEVI uint32_t block_rank(bool pred, uint32_t *lds4, uint32_t &total) {
+    const unsigned long long m = __ballot(pred);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __syncthreads();                       // lds4 may still be read from the previous use
+    if (lane == 0) lds4[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const uint32_t c0 = lds4[0], c1 = lds4[1], c2 = lds4[2], c3 = lds4[3];
+    total = c0 + c1 + c2 + c3;
+    const uint32_t before = wave == 0 ? 0u : (wave == 1 ? c0 : (wave == 2 ? c0 + c1 : c0 + c1 + c2));
+    return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// Per-frame constants of the spheres as seen from the camera: (oc.xyz, c) with oc = camera - centre and
+// c = dot(oc,oc) - r*r, the values every primary ray would compute (frag:234,236).
+__global__ void primary_sphere_kernel(RtLaunch L, float4 *__restrict__ prim) {
+    const uint32_t i = threadIdx.x;
+    if (i >= NUM_SPHERES) return;
+    const float4 s = c_spheres[i];
+    const f3 oc = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]) - F3(s.x, s.y, s.z);
+    prim[i] = make_float4(oc.x, oc.y, oc.z, dot3(oc, oc) - s.w * s.w);
+}
+
+template <bool D0>
+__global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles) {
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t lds_base;
+    __shared__ float4 lds_sph[NUM_SPHERES];
+    stage_sphere_table(lds_sph, D0 ? WS.prim : c_spheres);
+    const uint32_t cur = depth & 1u;
+    float4 *__restrict__ A = WS.pos_seed[cur];
+    float4 *__restrict__ B = WS.dir_pix[cur];
+    const uint32_t lo = blockIdx.x * RANGE;
+    const uint32_t count = D0 ? min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u) : WS.live[cur][blockIdx.x];
+    for (uint32_t off = 0; off < count; off += 256u) {
+        const uint32_t slot = lo + off + threadIdx.x;
+        bool valid = off + threadIdx.x < count;
+        Ray ray;
+        float closest = __builtin_inff();
+        uint32_t closest_i = 0;
+        bool enter = false;
+        if (D0) {
+            const PixelId p = pixel_of(L, blockIdx.x * (RANGE / 256u) + off / 256u, threadIdx.x);
+            valid = p.active;
+            float seed_base = 0.0f;
+            ray.pos = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]);
+            ray.dir = F3(0.0f, 0.0f, 1.0f);
+            if (valid) {
+                float nx, ny;
+                pixel_ndc(L, p, nx, ny);
+                generate_ray(L.u, nx, ny, ray.dir, seed_base);
+            }
+            A[slot] = make_float4(ray.pos.x, ray.pos.y, ray.pos.z, seed_base);
+            B[slot] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, u2f(valid ? (uint32_t)p.pi : 0xFFFFFFFFu));
+            WS.color[cur][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            if (valid) {
+                ray.inv = rcp3(ray.dir);
+                intersect_spheres_primary(lds_sph, ray.dir, closest, closest_i);
+                enter = root_box_test(S, ray, closest);
+            }
+        } else if (valid) {
+            const float4 a = A[slot], b = B[slot];
+            ray.pos = F3(a.x, a.y, a.z);
+            ray.dir = F3(b.x, b.y, b.z);
+            ray.inv = rcp3(ray.dir);
+            intersect_spheres(lds_sph, ray, closest, closest_i);
+            enter = root_box_test(S, ray, closest);
+        }
+        if (D0 || valid) {
+            WS.t[slot] = closest;
+            WS.sphere[slot] = closest_i;
+            WS.tri[slot] = 0u;
+        }
+        uint32_t total;
+        const uint32_t rank = block_rank(enter, lds4, total);
+        if (total) {   // workgroup-uniform
+            if (threadIdx.x == 0) lds_base = atomicAdd(&WS.ctr[QT_COUNT + cur], total);
+            __syncthreads();
+            if (enter) WS.qt[lds_base + rank] = slot;
+        }
+    }
+}
+
+template <int LEVELS, bool COUNT>
+__global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth) {
+    __shared__ uint32_t lds_stack[LEVELS * 256];
+    LevelStack st;
+    st.col = &lds_stack[threadIdx.x];
+    st.sp = 0;
+    const uint32_t cur = depth & 1u;
+    const float4 *__restrict__ A = WS.pos_seed[cur];
+    const float4 *__restrict__ B = WS.dir_pix[cur];
+    uint32_t *ctr = WS.ctr;
+    const uint32_t qt_count = ctr[QT_COUNT + cur];
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    bool has = false, exhausted = false;       // exhausted, batch_next, batch_end are wave-uniform
+    uint32_t batch_next = 0, batch_end = 0;
+    uint32_t slot = 0, closest_tri = 0;
+    float closest = 0.0f;
+    bool tri_hit = false;
+    Ray ray;
+    ray.pos = ray.dir = ray.inv = F3(0.0f, 0.0f, 0.0f);
+    for (;;) {
+        unsigned long long busy = __ballot(has);
+        if (!exhausted && 64 - __popcll(busy) >= REFILL_IDLE) {
+            if (batch_next == batch_end) {           // reserve the next batch of queue entries for this wave
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctr[QT_HEAD + cur], TRAVERSE_BATCH);
+                base = __shfl(base, 0, 64);
+                batch_next = base < qt_count ? base : qt_count;
+                batch_end = base + TRAVERSE_BATCH < qt_count ? base + TRAVERSE_BATCH : qt_count;
+                if (batch_next == batch_end) exhausted = true;
+            }
+            const uint32_t my = batch_next + (uint32_t)__popcll(~busy & lt_mask);
+            if (!has && my < batch_end) {
+                slot = WS.qt[my];
+                const float4 a = A[slot], b = B[slot];
+                ray.pos = F3(a.x, a.y, a.z);
+                ray.dir = F3(b.x, b.y, b.z);
+                ray.inv = rcp3(ray.dir);
+                closest = WS.t[slot];
+                closest_tri = 0; tri_hit = false;
+                st.reset_to_root();
+                has = true;
+                if (COUNT) cn.entered++;
+            }
+            const uint32_t taken = min(64u - (uint32_t)__popcll(busy), batch_end - batch_next);
+            batch_next += taken;
+            busy = __ballot(has);
+        }
+        if (busy == 0) { if (exhausted) break; else continue; }
+        if (has) {
+            visit_node<COUNT>(S, ray, st, closest, closest_tri, tri_hit, cn);
+            if (st.empty()) {
+                WS.t[slot] = closest;
+                if (tri_hit) WS.tri[slot] = closest_tri | 0x80000000u;
+                has = false;
+            }
+        }
+    }
+    if (COUNT && L.counters) flush_counters(L.counters, cn);
+}
+
+template <bool D0, bool COUNT>
+__global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles, uint32_t track_alive) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t cur = depth & 1u, nxt = cur ^ 1u;
+    const float4 *__restrict__ A = WS.pos_seed[cur];
+    const float4 *__restrict__ B = WS.dir_pix[cur];
+    const float4 *__restrict__ C = WS.color[cur];
+    uint32_t *ctr = WS.ctr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[QT_COUNT + nxt] = 0; ctr[QT_HEAD + nxt] = 0; }   // next depth's traversal queue
+    const uint32_t lo = blockIdx.x * RANGE;
+    const uint32_t count = D0 ? min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u) : WS.live[cur][blockIdx.x];
+    uint32_t out_count = 0;    // workgroup-uniform: survivors of this range so far
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    for (uint32_t off = 0; off < count; off += 256u) {
+        const uint32_t slot = lo + off + threadIdx.x;
+        bool valid = off + threadIdx.x < count;
+        bool cont = false;
+        float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;
+        if (valid) {
+            const float4 a = A[slot], b = B[slot];
+            const uint32_t pix = f2u(b.w);
+            valid = pix != 0xFFFFFFFFu;
+            if (valid) {
+                const float4 c = C[slot];
+                Ray ray;
+                ray.pos = F3(a.x, a.y, a.z);
+                ray.dir = F3(b.x, b.y, b.z);
+                ray.inv = rcp3(ray.dir);
+                Seed seed;
+                seed.base = a.w; seed.k = 0;
+                f3 color = F3(c.x, c.y, c.z);
+                const float closest = WS.t[slot];
+                const uint32_t closest_i = WS.sphere[slot];
+                const uint32_t tri_word = WS.tri[slot];
+                if (COUNT) cn.rays++;
+                PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
+                const Hit h = finish_intersection<COUNT>(S, L.u, ray, closest, closest_i, tri_word & 0x7FFFFFFFu, (tri_word >> 31) != 0, D0 ? &tap : nullptr, cn);
+                if (D0) {
+                    if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
+                    if (L.hit_kind) L.hit_kind[pix] = tap.kind;
+                    if (L.hit_slot) L.hit_slot[pix] = tap.slot;
+                    if (L.hit_t) L.hit_t[pix] = tap.t;
+                }
+                bool done = false;
+                if (!h.has_hit) {
+                    color = color * sample_sky(S, ray.dir);
+                    done = true;
+                } else {
+                    scatter(L.u, h, ray, color, seed);
+                    done = depth + 1u >= L.u.max_recursion_limit;
+                }
+                if (done) {
+                    write_pixel(L, pix, tonemap(color));
+                    if (L.n_rays) L.n_rays[pix] = depth + 1u;
+                } else {
+                    cont = true;
+                    na = make_float4(ray.pos.x, ray.pos.y, ray.pos.z, seed.base);
+                    nb = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, b.w);
+                    nc = make_float4(color.x, color.y, color.z, 0.0f);
+                }
+            }
+        }
+        uint32_t total;
+        const uint32_t rank = block_rank(cont, lds4, total);
+        if (cont) {
+            const uint32_t ni = lo + out_count + rank;   // never ahead of the slots this workgroup still has to read: other planes
+            WS.pos_seed[nxt][ni] = na;
+            WS.dir_pix[nxt][ni] = nb;
+            WS.color[nxt][ni] = nc;
+        }
+        out_count += total;
+    }
+    if (threadIdx.x == 0) {
+        WS.live[nxt][blockIdx.x] = out_count;
+        if (track_alive && out_count) atomicAdd(&ctr[ALIVE], out_count);
+    }
+    if (COUNT && L.counters) flush_counters(L.counters, cn);
+}
+
+template <int LEVELS>
+int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid) {
+    if (L.counters) hipLaunchKernelGGL((render_kernel<LEVELS, true>), grid, dim3(256), 0, st, S, L);
+    else hipLaunchKernelGGL((render_kernel<LEVELS, false>), grid, dim3(256), 0, st, S, L);
     return (int)hipGetLastError();
+}
+
+template <int LEVELS>
+void launch_traverse(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace &WS, uint32_t d, hipStream_t st, dim3 grid) {
+    if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true>), grid, dim3(256), 0, st, S, L, WS, d);
+    else hipLaunchKernelGGL((traverse_kernel<LEVELS, false>), grid, dim3(256), 0, st, S, L, WS, d);
 }
 
 }  // namespace
 
-int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, void *stream, const char **err) {
+size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows) {
+    const size_t n_tiles = (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u);
+    return (n_tiles + RANGE / 256u - 1) / (RANGE / 256u);
+}
+size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows) { return rt_workspace_ranges(width, n_local_rows) * RANGE; }
+
+int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace *WS, void *stream, const char **err) {
     const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
     if (tiles_x == 0 || tiles_y == 0) return 0;
-    const dim3 grid(tiles_x * tiles_y);
+    const uint32_t n_tiles = tiles_x * tiles_y;
     hipStream_t st = (hipStream_t)stream;
-    // a visit pushes at most 8 children and pops one: the stack never exceeds 7*levels + 1 entries
-    const uint32_t need = 7u * (S.max_depth + 1u) + 1u;
-    int rc;
-    if (need <= 64) rc = launch_with_stack<64>(S, L, st, grid);
-    else if (need <= 160) rc = launch_with_stack<160>(S, L, st, grid);
-    else rc = launch_with_stack<7 * (RT_MAX_TREE_DEPTH + 1) + 1>(S, L, st, grid);
+    // the traversal stack holds at most one entry per tree level (the root's virtual level included)
+    const uint32_t need = S.max_depth + 2u;
+    int rc = 0;
+    if (!WS) {
+        const dim3 grid(n_tiles);
+        if (need <= 12) rc = launch_megakernel<12>(S, L, st, grid);
+        else if (need <= 20) rc = launch_megakernel<20>(S, L, st, grid);
+        else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid);
+    } else {
+        const bool count = L.counters != nullptr;
+        const dim3 grid((uint32_t)rt_workspace_ranges(L.width, L.n_local_rows));   // one workgroup per slot range
+        const dim3 tgrid(256 * TRAVERSE_WG_PER_CU);                                  // persistent traversal workgroups
+        (void)hipMemsetAsync(WS->ctr, 0, 8 * sizeof(uint32_t), st);
+        hipLaunchKernelGGL(primary_sphere_kernel, dim3(1), dim3(128), 0, st, L, WS->prim);
+        const uint32_t limit = L.u.max_recursion_limit;
+        for (uint32_t d = 0; d < limit; d++) {
+            // Paths rarely live long; past a few bounces ask the device now and then whether any is left.
+            const bool ask = d >= 7 && d + 1 < limit && (d & 3u) == 3u;
+            if (ask) (void)hipMemsetAsync(&WS->ctr[ALIVE], 0, sizeof(uint32_t), st);
+            if (d == 0) hipLaunchKernelGGL((spheres_kernel<true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
+            else hipLaunchKernelGGL((spheres_kernel<false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
+            if (S.n_nodes) {
+                if (need <= 12) launch_traverse<12>(S, L, *WS, d, st, tgrid);
+                else if (need <= 20) launch_traverse<20>(S, L, *WS, d, st, tgrid);
+                else launch_traverse<RT_MAX_TREE_DEPTH + 2>(S, L, *WS, d, st, tgrid);
+            }
+            const uint32_t track = ask ? 1u : 0u;
+            if (d == 0) {
+                if (count) hipLaunchKernelGGL((shade_kernel<true, true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
+                else hipLaunchKernelGGL((shade_kernel<true, false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
+            } else {
+                if (count) hipLaunchKernelGGL((shade_kernel<false, true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
+                else hipLaunchKernelGGL((shade_kernel<false, false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
+            }
+            if (ask) {
+                uint32_t left = 0;
+                if (hipMemcpyAsync(&left, &WS->ctr[ALIVE], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) break;
+                if (left == 0) break;
+            }
+        }
+        rc = (int)hipGetLastError();
+    }
     if (rc != 0) { if (err) *err = hipGetErrorString((hipError_t)rc); return rc; }
     return 0;
 }

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Time rt_render on device memory for a few scene/parameter variants (development aid)."""
+import argparse, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from raytracer_amd import api, scenes
+from raytracer_amd.camera import Camera
+from raytracer_amd.params import Uniforms
+
+def empty_scene():
+    z = np.zeros(3, np.float32)
+    return dict(vertices=np.zeros((0, 4), np.float32), normals=np.zeros((0, 4), np.float32), tri_refs=np.zeros((0, 4), np.uint32), nodes=np.zeros(0, np.uint32), bounds_min=z, bounds_max=z)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", default="empty,bunny")
+    ap.add_argument("--limits", default="1,2,5")
+    ap.add_argument("--width", type=int, default=3840); ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--count", action="store_true")
+    ap.add_argument("--pipelines", default="wavefront,megakernel")
+    ap.add_argument("--subframes", type=int, default=4)
+    a = ap.parse_args()
+    sky = scenes.procedural_skybox(900)
+    W, H = a.width, a.height
+    color = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    for name in a.scenes.split(","):
+        d = empty_scene() if name == "empty" else {"bunny": scenes.default_octree, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "small": scenes.small_test_scene}[name]().as_dict()
+        sc = api.Scene.from_dict(d); sc.set_skybox(sky); sc.set_subframes(a.subframes)
+        for pipe, lim in [(p, int(x)) for p in a.pipelines.split(",") for x in a.limits.split(",")]:
+            sc.set_pipeline(pipe)
+            def run(k, sync=False):
+                u = Uniforms.from_camera(Camera(aspect=W / H), time=k / 60.0, max_recursion_limit=lim).pack()
+                fr = api.make_frame(u, W, H, accum_index=k + 1, stream=torch.cuda.current_stream().cuda_stream)
+                tg = api.rt_target(); tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, int(sync), color.data_ptr()
+                sc.render_raw(fr, tg)
+            run(0); run(1); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(a.reps): run(k)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / a.reps * 1e3
+            extra = ""
+            if a.count:
+                sc.set_counting(True); run(0, True); st = sc.stats(); sc.set_counting(False)
+                extra = f" rays={st['rays']} Mrays/s={st['rays'] / ms / 1e3:.0f} pops={st['node_pops']} tri={st['triangle_tests']} box={st['child_box_tests']} enter={st['rays_entering_octree']}"
+            print(f"{name:8s} {pipe:10s} limit={lim} {W}x{H}: {ms:.3f} ms/frame{extra}", flush=True)
+        sc.close()
+
+if __name__ == "__main__":
+    main()
