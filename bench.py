@@ -29,21 +29,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BAND_ROWS = 16
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak
 VALU_PEAK_TFLOPS_NO_FMA = 78.6  # 157.3 TFLOP/s fp32 vector peak counts an FMA as 2; this path may not fuse
+CPU_BASELINE_SECONDS = 12.0     # the CPU leg renders whole frames of the same workload until this much time has passed
 
 
-def algorithmic_bytes(st: dict, pixels: int, blended: bool) -> int:
-    """Bytes the reference's data layout moves for the counted work: per node visit 2 header words + 4 B per child
-    pointer; per triangle test a 16 B index record + three 16 B vertices; per shaded triangle hit index + 3 vertices +
-    3 normals (112 B); per pixel a 16 B colour write (+16 B read when blending with n > 1)."""
-    return (8 * st["node_pops"] + 4 * st["child_box_tests"] + 64 * st["triangle_tests"] + 112 * st["triangle_hits_shaded"]
-            + pixels * (16 + (16 if blended else 0)))
+def traversal_bytes(st: dict) -> int:
+    """Bytes the reference's data layout moves for the counted octree work: per node visit 2 header words + 4 B per
+    child pointer; per triangle test a 16 B index record + three 16 B vertices."""
+    return 8 * st["node_pops"] + 4 * st["child_box_tests"] + 64 * st["triangle_tests"]
+
+
+def frame_bytes(st: dict, pixels: int, blended: bool) -> int:
+    """traversal_bytes + per shaded triangle hit index + 3 vertices + 3 normals (112 B) + per pixel a 16 B colour
+    write (+16 B read when blending with n > 1)."""
+    return traversal_bytes(st) + 112 * st["triangle_hits_shaded"] + pixels * (16 + (16 if blended else 0))
 
 
 def algorithmic_flops(st: dict) -> int:
     """Approximate arithmetic of the counted tests: sphere 17 flop x 84 per ray, child box 27, triangle 50."""
     return 84 * 17 * st["rays"] + 27 * st["child_box_tests"] + 50 * st["triangle_tests"]
+
+
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this command, or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -55,6 +70,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--max-recursion-limit", type=int, default=2)
     ap.add_argument("--scene", default="bunny", choices=["bunny", "synthetic_100k", "synthetic_1m"])
+    ap.add_argument("--pipeline", default="persistent", choices=["persistent", "wavefront", "megakernel"])
+    ap.add_argument("--subframes", type=int, default=None)
+    ap.add_argument("--per-frame-calls", action="store_true", help="N = 1: one rt_render per step instead of one rt_render_sequence over the K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,6 +107,9 @@ def main():
     sky = scene_arrays["sky"]
     sc = api.Scene.from_dict(scene_arrays, device=local_rank)
     sc.set_skybox(sky)
+    sc.set_pipeline(args.pipeline)
+    if args.subframes:
+        sc.set_subframes(args.subframes)
     t_build = time.time() - t_build
 
     W, H = args.width, args.height
@@ -103,11 +124,16 @@ def main():
     color = torch.zeros((rows_pad, W, 4), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def render(step, accum_index, sync=False):
-        fr = api.make_frame(uniforms(step), W, H, accum_index=accum_index, blend=True, band=(BAND_ROWS, parts, rank), stream=stream, compact=parts > 1)
+    def frame_of(step, accum_index):
+        return api.make_frame(uniforms(step), W, H, accum_index=accum_index, blend=True, band=(BAND_ROWS, parts, rank), stream=stream, compact=parts > 1)
+
+    def target_of(sync=False):
         tg = api.rt_target()
         tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, int(sync), color.data_ptr()
-        sc.render_raw(fr, tg)
+        return tg
+
+    def render(step, accum_index, sync=False):
+        sc.render_raw(frame_of(step, accum_index), target_of(sync))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -115,23 +141,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        render(k, k + 1)
-        if world > 1:
-            rdist.gather_frame(color, H, BAND_ROWS)
+    # One step = one frame.  On one GPU the K frames are the library's progressive-accumulation sequence (one
+    # rt_render_sequence call: consecutive frames of a still camera pipeline inside the library); on several GPUs
+    # every frame's bands are gathered to rank 0, so frames are issued one by one.
+    sequence = world == 1 and not args.per_frame_calls
+
+    def run_steps(first, n):
+        if sequence:
+            sc.render_sequence_raw([frame_of(first + k, first + k + 1) for k in range(n)], target_of())
+        else:
+            for k in range(n):
+                render(first + k, first + k + 1)
+                if world > 1:
+                    rdist.gather_frame(color, H, BAND_ROWS)
+
+    if args.warmup:
+        run_steps(0, args.warmup)
     sync_all()
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+    # the dominant kernel's launches are bracketed with HIP events on their own streams inside the library
+    sc.set_kernel_timing(True)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[2 * k].record()
-        render(k, k + 1)
-        ev[2 * k + 1].record()
-        if world > 1:
-            rdist.gather_frame(color, H, BAND_ROWS)
+    run_steps(0, args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
-    kernel_ms = [ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(args.steps)]
+    k_total_ms, k_launches = sc.kernel_time()
+    sc.set_kernel_timing(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -166,30 +201,41 @@ def main():
         "work_per_frame": {k: v / args.steps for k, v in tot.items()},
         "scene_build_s": round(t_build, 3),
     }
-    # ---- roofline of the dominant (only) kernel, this rank's launches -------------------------------------------
-    k_ms = float(np.mean(kernel_ms))
+    out["config"]["pipeline"] = args.pipeline
+    out["config"]["issue"] = "rt_render_sequence over the K steps" if sequence else "one rt_render per step"
+    # ---- roofline of the dominant kernel, this rank's launches --------------------------------------------------
+    kernel = {"wavefront": "traverse_kernel", "megakernel": "render_kernel", "persistent": "path_kernel"}[args.pipeline]
+    k_ms = k_total_ms / max(k_launches, 1)
     px_local = W * min(rows_local, H) if parts > 1 else W * H
-    per_launch = {k: v / args.steps for k, v in local_tot.items()}
-    abytes = algorithmic_bytes(per_launch, px_local, blended=True)
-    aflops = algorithmic_flops(per_launch)
-    achieved = abytes / (k_ms * 1e-3) / 1e9
-    out["roofline"] = {"kernel": "render_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(abytes),
-                       "note": "the path is VALU-bound, not HBM-bound: see valu"}
-    out["valu"] = {"achieved_tflops": round(aflops / (k_ms * 1e-3) / 1e12, 3), "peak_tflops_no_fma": VALU_PEAK_TFLOPS_NO_FMA,
-                   "frac": round(aflops / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS_NO_FMA, 4), "algorithmic_flop_per_launch": int(aflops)}
+    local_work = {k: v for k, v in local_tot.items()}
+    total_bytes = traversal_bytes(local_work) if args.pipeline == "wavefront" else frame_bytes(local_work, px_local * args.steps, blended=True)
+    abytes = total_bytes / max(k_launches, 1)
+    achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    out["roofline"] = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(kernel), "kernel_ms": round(k_ms, 4),
+                       "launches": k_launches, "algorithmic_bytes_per_launch": int(abytes),
+                       "note": "octree traversal is bound by dependent-load latency and VALU issue, not by HBM bandwidth: see valu and DESIGN.md"}
+    aflops = algorithmic_flops(local_work) / args.steps
+    frame_ms = 1e3 * elapsed / args.steps
+    out["valu"] = {"scope": "whole frame", "achieved_tflops": round(aflops / (frame_ms * 1e-3) / 1e12, 3), "peak_tflops_no_fma": VALU_PEAK_TFLOPS_NO_FMA,
+                   "frac": round(aflops / (frame_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS_NO_FMA, 4), "algorithmic_flop_per_frame": int(aflops)}
 
     # ---- CPU baseline: the oracle (a port of the shader with the reference vehicle's numerics) on this host -----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         osc = oracle.OracleScene(scene_arrays, sky)
         threads = min(16, os.cpu_count() or 1)
+        n_rays, n_frames = 0, 0
         t1 = time.perf_counter()
-        o = osc.render(uniforms(0), W, H, taps=False, threads=threads)
-        dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(o["counters"]["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                               "sample": f"one full {W}x{H} frame of the same workload ({o['counters']['rays']} rays) in {dt:.2f} s"}
-        # cross-check a strip of rows of frame 0 against the GPU (checker only)
+        while True:
+            o = osc.render(uniforms(n_frames), W, H, taps=False, threads=threads)
+            n_rays += int(o["counters"]["rays"])
+            n_frames += 1
+            dt = time.perf_counter() - t1
+            if dt >= CPU_BASELINE_SECONDS:
+                break
+        out["cpu_baseline"] = {"value": round(n_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": f"{n_frames} consecutive {W}x{H} frames of the same workload (time = k/60 s; {n_rays} rays) in {dt:.1f} s"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

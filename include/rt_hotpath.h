@@ -126,20 +126,39 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert,
  * Without a skybox texture() returns 0 like an unbound texture. */
 int rt_skybox_set(rt_scene *scene, const uint8_t *const faces[6], int w, int h);
 int rt_render(rt_scene *scene, const rt_frame *frame, const rt_target *target);
+/* The reference's progressive accumulation (App::Render called once per displayed frame with an unchanged camera,
+ * App.cpp:103-140, blending 1/n at ray_tracer.frag:655-656) as one call: renders frames[0..n_frames) in order into
+ * the same target; pixel values are identical to n_frames rt_render calls.  All frames must agree in width, height,
+ * band selection, compact_rows, ndc tables and stream; uniforms, accum_index and blend may differ.  With the
+ * wavefront pipeline and more than one sub-frame the sub-frame chains of consecutive frames are pipelined (a pixel's
+ * frames stay ordered), which a caller issuing one rt_render per frame on one stream cannot get.  Host-memory
+ * targets are uploaded once before and downloaded once after the sequence. */
+int rt_render_sequence(rt_scene *scene, const rt_frame *frames, size_t n_frames, const rt_target *target);
 /* Number of rows a compact band buffer holds for this frame's band selection (whole strips; the last strip may
  * extend past `height`, those rows are never written). */
 uint32_t rt_band_row_count(const rt_frame *frame);
 int rt_scene_stats(rt_scene *scene, rt_stats *out);   /* counters of the last rt_render with sync = 1 or after a stream sync */
 /* Enables (1) / disables (0) work counters for subsequent renders of this scene (default off: counting costs time). */
 int rt_scene_set_counting(rt_scene *scene, int enabled);
-/* Selects how a frame is executed (results are identical): RT_PIPELINE_WAVEFRONT (default) runs one pass per path
- * depth -- sphere tests, a persistent octree-traversal kernel fed from a queue, shading with compaction of the
- * surviving paths; RT_PIPELINE_MEGAKERNEL traces a pixel's whole path in one lane of one kernel. */
-enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1 };
+/* Measurement aid (no counterpart in the reference): while enabled, every launch of the dominant kernel -- the octree
+ * traversal kernel of the wavefront pipeline, the single kernel of the megakernel pipeline -- is bracketed by HIP
+ * events on the stream it is launched on (at most 4096 launches per sub-frame stream are kept between reads).
+ * rt_scene_kernel_time synchronises the device, returns the summed duration and the number of launches since the last
+ * read, and clears the record. */
+int rt_scene_set_kernel_timing(rt_scene *scene, int enabled);
+int rt_scene_kernel_time(rt_scene *scene, double *total_ms, uint32_t *launches);
+/* Selects how a frame is executed (results are bit-identical):
+ *   RT_PIPELINE_PERSISTENT (default)  one kernel of resident waves; every lane carries one path at a time, lanes
+ *       alternate between octree traversal and a batched "segment block" (hit assembly, scattering, next pixel,
+ *       sphere tests), and free lanes take new pixels from global tile counters;
+ *   RT_PIPELINE_WAVEFRONT  one pass per path depth: sphere tests, a persistent octree-traversal kernel fed from a
+ *       queue, shading with compaction of the surviving paths into the next depth's queue;
+ *   RT_PIPELINE_MEGAKERNEL  a pixel's whole path in one lane of one kernel (the simple cross-check). */
+enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1, RT_PIPELINE_PERSISTENT = 2 };
 int rt_scene_set_pipeline(rt_scene *scene, int pipeline);
-/* Wavefront pipeline only: a frame is rendered as up to n (1..8, default 4) interleaved sub-frames whose kernel
- * chains run on separate internal streams, forked from and joined to rt_frame.stream, so that the sparse end of one
- * chain overlaps the dense kernels of another.  Results do not depend on n. */
+/* Persistent and wavefront pipelines: a frame is rendered as up to n (1..8, default 2) interleaved sub-frames whose
+ * kernels run on separate internal streams, forked from and joined to rt_frame.stream, so that the sparse end of one
+ * sub-frame overlaps dense work of another (most effective inside rt_render_sequence).  Results do not depend on n. */
 int rt_scene_set_subframes(rt_scene *scene, int n);
 int rt_scene_destroy(rt_scene *scene);
 

@@ -28,8 +28,8 @@ RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = range(6)
 
 EXPORTED_SYMBOLS = [
-    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_band_row_count", "rt_scene_stats",
-    "rt_scene_set_counting", "rt_scene_set_pipeline", "rt_scene_set_subframes", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_free",
+    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_band_row_count", "rt_scene_stats",
+    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_set_subframes", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_free",
 ]
 
 
@@ -86,10 +86,13 @@ def lib():
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.rt_skybox_set.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_frame), C.POINTER(rt_target)]
+        L.rt_render_sequence.argtypes = [C.c_void_p, C.POINTER(rt_frame), C.c_size_t, C.POINTER(rt_target)]
         L.rt_band_row_count.argtypes = [C.POINTER(rt_frame)]
         L.rt_band_row_count.restype = C.c_uint32
         L.rt_scene_stats.argtypes = [C.c_void_p, C.POINTER(rt_stats)]
         L.rt_scene_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rt_scene_set_pipeline.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_set_subframes.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
@@ -228,9 +231,18 @@ class Scene:
     def set_counting(self, enabled: bool):
         _check(lib().rt_scene_set_counting(self._h, int(enabled)))
 
+    def set_kernel_timing(self, enabled: bool):
+        _check(lib().rt_scene_set_kernel_timing(self._h, int(enabled)))
+
+    def kernel_time(self):
+        """(summed ms, launches) of the dominant kernel since the last read; synchronises the device."""
+        ms, n = C.c_double(), C.c_uint32()
+        _check(lib().rt_scene_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def set_pipeline(self, name: str):
-        """'wavefront' (default) or 'megakernel'; results are identical."""
-        _check(lib().rt_scene_set_pipeline(self._h, {"megakernel": 0, "wavefront": 1}[name]))
+        """'persistent' (default), 'wavefront' or 'megakernel'; results are identical."""
+        _check(lib().rt_scene_set_pipeline(self._h, {"megakernel": 0, "wavefront": 1, "persistent": 2}[name]))
 
     def set_subframes(self, n: int):
         _check(lib().rt_scene_set_subframes(self._h, n))
@@ -242,6 +254,11 @@ class Scene:
 
     def render_raw(self, frame: rt_frame, target: rt_target):
         _check(lib().rt_render(self._h, C.byref(frame), C.byref(target)))
+
+    def render_sequence_raw(self, frames, target: rt_target):
+        """Consecutive accumulation frames into one target in one call (frames: list of rt_frame)."""
+        arr = (rt_frame * len(frames))(*frames)
+        _check(lib().rt_render_sequence(self._h, arr, len(frames), C.byref(target)))
 
     def render(self, uniforms, width: int, height: int, *, accum_index: int = 1, blend: bool = True, color: np.ndarray | None = None,
                planes: bool = True, ndc=None, band=(16, 1, 0)) -> dict:
@@ -316,3 +333,15 @@ class RenderPass:
         tg.memory, tg.sync = RT_MEM_DEVICE, int(sync)
         tg.color, tg.depth = self.color_ptr, self.depth_ptr
         self.scene.render_raw(fr, tg)
+
+    def RenderFrames(self, uniforms_per_frame, sync: bool = False):
+        """len(uniforms_per_frame) consecutive Render calls (camera unchanged, time advancing) issued as one sequence."""
+        frames = []
+        for uniforms in uniforms_per_frame:
+            u = uniforms.pack() if isinstance(uniforms, Uniforms) else uniforms
+            frames.append(make_frame(u, self.width, self.height, accum_index=self.m_still_frame_counter, blend=True, band=self.band, stream=self.stream))
+            self.m_still_frame_counter += 1
+        tg = rt_target()
+        tg.memory, tg.sync = RT_MEM_DEVICE, int(sync)
+        tg.color, tg.depth = self.color_ptr, self.depth_ptr
+        self.scene.render_sequence_raw(frames, tg)

@@ -5,6 +5,8 @@
 #include <xmmintrin.h>
 #include <pmmintrin.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -54,15 +56,18 @@ struct rt_scene {
     size_t s_pixels = 0;
     // wavefront pipeline: a frame is cut into up to RT_MAX_SUBFRAMES interleaved sub-frames that run as independent
     // kernel chains on their own streams, so that the sparse tail of one chain overlaps the dense kernels of another
-    int pipeline = RT_PIPELINE_WAVEFRONT;
-    int subframes = 4;
+    int pipeline = RT_PIPELINE_PERSISTENT;
+    int subframes = 2;
     struct Sub {
         RtWorkspace ws{};
         void *block = nullptr;
         size_t slots = 0;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        RtProbe probe{};
+        uint32_t *pool = nullptr;   // tile counter of the persistent path kernel
     } sub[RT_MAX_SUBFRAMES];
+    bool timing = false;
     hipEvent_t fork_ev = nullptr;
 };
 
@@ -132,6 +137,59 @@ int flatten_nodes(const uint32_t *words, size_t n_words, size_t n_ref, const flo
     return RT_OK;
 }
 
+// Frame-space pixel rectangle (x0, y0, x1, y1 inclusive) that the scene's octree bounds project to under the frame's
+// camera, padded; false when it is empty.  A scheduling hint only (which pixels to start first), so double-precision
+// host arithmetic on the inverse of the shader's inverse view-projection matrix is good enough.
+bool octree_screen_rect(const RtDeviceScene &d, const rt_uniforms &u, uint32_t width, uint32_t height, uint32_t rect[4]) {
+    if (d.n_nodes == 0) return false;
+    double a[4][8];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = u.inv_view_proj_mat[c * 4 + r]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int i = 0; i < 4; i++) {   // Gauss-Jordan with partial pivoting
+        int piv = i;
+        for (int r = i + 1; r < 4; r++) if (std::fabs(a[r][i]) > std::fabs(a[piv][i])) piv = r;
+        if (!(std::fabs(a[piv][i]) > 1e-300)) { rect[0] = 0; rect[1] = 0; rect[2] = width - 1; rect[3] = height - 1; return true; }
+        if (piv != i) for (int c = 0; c < 8; c++) std::swap(a[i][c], a[piv][c]);
+        const double inv = 1.0 / a[i][i];
+        for (int c = 0; c < 8; c++) a[i][c] *= inv;
+        for (int r = 0; r < 4; r++) if (r != i) { const double f = a[r][i]; if (f != 0.0) for (int c = 0; c < 8; c++) a[r][c] -= f * a[i][c]; }
+    }
+    double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+    double q[8][4];
+    for (int k = 0; k < 8; k++) {
+        const double p[4] = {k & 1 ? d.bounds_max[0] : d.bounds_min[0], k & 2 ? d.bounds_max[1] : d.bounds_min[1], k & 4 ? d.bounds_max[2] : d.bounds_min[2], 1.0};
+        for (int r = 0; r < 4; r++) q[k][r] = a[r][4] * p[0] + a[r][5] * p[1] + a[r][6] * p[2] + a[r][7] * p[3];
+    }
+    const double w_min = 1e-4;   // the box is clipped against the plane w = w_min in front of the eye
+    auto add = [&](const double *c) {
+        const double px = (c[0] / c[3] + 1.0) * 0.5 * width, py = (c[1] / c[3] + 1.0) * 0.5 * height;
+        x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+    };
+    for (int k = 0; k < 8; k++) {
+        if (q[k][3] >= w_min) add(q[k]);
+        for (int ax = 0; ax < 3; ax++) {   // the three edges leaving corner k towards a higher corner index
+            const int j = k | (1 << ax);
+            if (j == k || (q[k][3] >= w_min) == (q[j][3] >= w_min)) continue;
+            const double t = (w_min - q[k][3]) / (q[j][3] - q[k][3]);
+            const double c[4] = {q[k][0] + t * (q[j][0] - q[k][0]), q[k][1] + t * (q[j][1] - q[k][1]), q[k][2] + t * (q[j][2] - q[k][2]), w_min};
+            add(c);
+        }
+    }
+    if (!(x1 >= x0)) return false;   // the whole box is behind the eye
+    x0 -= 8.0; y0 -= 8.0; x1 += 8.0; y1 += 8.0;
+    if (!(x1 >= 0.0 && y1 >= 0.0 && x0 <= width - 1.0 && y0 <= height - 1.0)) return false;
+    rect[0] = (uint32_t)std::max(x0, 0.0); rect[1] = (uint32_t)std::max(y0, 0.0);
+    rect[2] = (uint32_t)std::min(x1, width - 1.0); rect[3] = (uint32_t)std::min(y1, height - 1.0);
+    return true;
+}
+
+// The same rectangle in 16x16 tiles of the local rows of one band part (strips of band_rows rows, every parts-th).
+void hot_tiles(const uint32_t rect[4], bool any, uint32_t band_rows, uint32_t parts, uint32_t hot[4]) {
+    hot[0] = 1; hot[1] = 1; hot[2] = 0; hot[3] = 0;
+    if (!any) return;
+    const uint32_t lr0 = (rect[1] / band_rows / parts) * band_rows, lr1 = (rect[3] / band_rows / parts + 1u) * band_rows - 1u;
+    hot[0] = rect[0] / 16u; hot[2] = rect[2] / 16u; hot[1] = lr0 / 16u; hot[3] = lr1 / 16u;
+}
+
 // One allocation carved into the workspace planes (256-byte aligned pieces).
 int ensure_workspace(rt_scene::Sub *s, size_t slots, size_t ranges) {
     if (s->slots >= slots && s->block) return RT_OK;
@@ -165,6 +223,14 @@ extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
 int rt_internal_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
+
+// Development hook (not part of the ABI): copies the tile-counter block of sub-frame 0 to the host.
+int rt_internal_read_pool(rt_scene *s, void *out, size_t bytes) {
+    if (!s || !s->sub[0].pool || bytes > rt_pool_bytes()) return fail(RT_EINVAL, "no pool");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, s->sub[0].pool, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 
 int rt_device_count(int *count) {
     if (!count) return fail(RT_EINVAL, "count is null");
@@ -265,7 +331,7 @@ int rt_skybox_set(rt_scene *s, const uint8_t *const faces[6], int w, int h) {
 
 int rt_scene_set_pipeline(rt_scene *s, int pipeline) {
     if (!s) return fail(RT_EINVAL, "scene is null");
-    if (pipeline != RT_PIPELINE_MEGAKERNEL && pipeline != RT_PIPELINE_WAVEFRONT) return fail(RT_EINVAL, "unknown pipeline %d", pipeline);
+    if (pipeline != RT_PIPELINE_MEGAKERNEL && pipeline != RT_PIPELINE_WAVEFRONT && pipeline != RT_PIPELINE_PERSISTENT) return fail(RT_EINVAL, "unknown pipeline %d", pipeline);
     s->pipeline = pipeline;
     return RT_OK;
 }
@@ -280,6 +346,43 @@ int rt_scene_set_subframes(rt_scene *s, int n) {
 int rt_scene_set_counting(rt_scene *s, int enabled) {
     if (!s) return fail(RT_EINVAL, "scene is null");
     s->counting = enabled != 0;
+    return RT_OK;
+}
+
+#define RT_PROBE_PAIRS 4096u
+int rt_scene_set_kernel_timing(rt_scene *s, int enabled) {
+    if (!s) return fail(RT_EINVAL, "scene is null");
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
+    if (enabled) {
+        for (rt_scene::Sub &sb : s->sub) {
+            if (!sb.probe.events) {
+                sb.probe.events = new hipEvent_t[2 * RT_PROBE_PAIRS]();
+                sb.probe.capacity = RT_PROBE_PAIRS;
+                for (uint32_t i = 0; i < 2 * RT_PROBE_PAIRS; i++) HIP_TRY(hipEventCreate(&sb.probe.events[i]));
+            }
+            sb.probe.used = 0;
+        }
+    }
+    s->timing = enabled != 0;
+    return RT_OK;
+}
+
+int rt_scene_kernel_time(rt_scene *s, double *total_ms, uint32_t *launches) {
+    if (!s || !total_ms || !launches) return fail(RT_EINVAL, "null argument");
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
+    HIP_TRY(hipDeviceSynchronize());
+    double ms = 0.0; uint32_t n = 0;
+    for (rt_scene::Sub &sb : s->sub) {
+        for (uint32_t i = 0; i < sb.probe.used; i++) {
+            float t = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&t, sb.probe.events[2 * i], sb.probe.events[2 * i + 1]));
+            ms += t; n++;
+        }
+        sb.probe.used = 0;
+    }
+    *total_ms = ms; *launches = n;
     return RT_OK;
 }
 
@@ -302,16 +405,29 @@ static uint32_t band_rows_of(const rt_frame *f) {
 }
 uint32_t rt_band_row_count(const rt_frame *f) { return band_rows_of(f); }
 
-int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
-    if (!s || !f || !t) return fail(RT_EINVAL, "null argument");
+// Frames of one sequence share everything that decides which pixels a launch owns and where they live.
+static bool same_geometry(const rt_frame &a, const rt_frame &b) {
+    return a.width == b.width && a.height == b.height && a.band_rows == b.band_rows && a.band_parts == b.band_parts &&
+           a.band_part == b.band_part && a.compact_rows == b.compact_rows && a.ndc_x == b.ndc_x && a.ndc_y == b.ndc_y && a.stream == b.stream;
+}
+
+static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, const rt_target *t) {
+    if (!s || !frames || !t) return fail(RT_EINVAL, "null argument");
+    if (n_frames == 0) return RT_OK;
+    const rt_frame *f = frames;
     if (!t->color) return fail(RT_EINVAL, "target colour plane is null");
     if (f->width == 0 || f->height == 0 || f->width > 65536 || f->height > 65536) return fail(RT_EINVAL, "frame size %ux%u out of range", f->width, f->height);
-    if (f->accum_index == 0) return fail(RT_EINVAL, "accum_index must be >= 1");
     if (f->band_parts == 0 || f->band_part >= f->band_parts || f->band_rows == 0) return fail(RT_EINVAL, "band selection %u/%u (rows %u) invalid", f->band_part, f->band_parts, f->band_rows);
     if (t->memory != RT_MEM_HOST && t->memory != RT_MEM_DEVICE) return fail(RT_EINVAL, "target memory kind %d unknown", t->memory);
     if ((f->ndc_x == nullptr) != (f->ndc_y == nullptr)) return fail(RT_EINVAL, "ndc_x and ndc_y must be given together");
     if (t->memory == RT_MEM_HOST && !t->sync) return fail(RT_EINVAL, "host-memory targets require sync = 1");
     if ((unsigned long long)f->width * f->height >= 0xFFFFFFFFull) return fail(RT_ELIMIT, "frame has too many pixels");
+    uint32_t min_limit = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n_frames; i++) {
+        if (frames[i].accum_index == 0) return fail(RT_EINVAL, "accum_index must be >= 1");
+        if (!same_geometry(frames[i], *f)) return fail(RT_EINVAL, "frame %zu of the sequence differs from frame 0 in size, band, ndc table or stream", i);
+        if (frames[i].u.max_recursion_limit < min_limit) min_limit = frames[i].u.max_recursion_limit;
+    }
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
     hipStream_t st = (hipStream_t)f->stream;
@@ -327,10 +443,11 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
 
     L.sub_parts = 1; L.sub_part = 0;
-    const bool wavefront = s->pipeline == RT_PIPELINE_WAVEFRONT && f->u.max_recursion_limit >= 1 && L.n_local_rows > 0;
+    const bool wavefront = s->pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
+    const bool persistent = s->pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
     // number of sub-frames: every one should still fill the machine (>= 64 strips of 16 rows x width)
     uint32_t K = 1;
-    if (wavefront) {
+    if (wavefront || persistent) {
         const uint32_t strips = L.n_local_rows / f->band_rows;
         K = (uint32_t)s->subframes;
         while (K > 1 && (size_t)(strips / K) * f->band_rows * f->width < ((size_t)1 << 19)) K--;
@@ -338,8 +455,12 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
             rt_frame fj = *f;
             fj.band_parts = f->band_parts * K; fj.band_part = j * f->band_parts + f->band_part;
             const uint32_t rows = band_rows_of(&fj);
-            int wrc = ensure_workspace(&s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
-            if (wrc != RT_OK) return wrc;
+            if (wavefront) {
+                int wrc = ensure_workspace(&s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
+                if (wrc != RT_OK) return wrc;
+            } else if (!s->sub[j].pool) {
+                HIP_TRY(hipMalloc((void **)&s->sub[j].pool, rt_pool_bytes()));
+            }
             if (K > 1 && !s->sub[j].stream) {
                 HIP_TRY(hipStreamCreateWithFlags(&s->sub[j].stream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&s->sub[j].done, hipEventDisableTiming));
@@ -347,21 +468,41 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
         }
         if (K > 1 && !s->fork_ev) HIP_TRY(hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
     }
-    // Enqueues the frame: the single-kernel pipeline, or K sub-frame chains forked from / joined to the caller's stream.
+    // Enqueues the sequence.  Single-kernel pipeline or one sub-frame: frame after frame on the caller's stream.
+    // Otherwise K sub-frame chains are forked from the caller's stream once, each runs its share of every frame
+    // in order on its own stream (a pixel belongs to one sub-frame, so its accumulation order is kept), and all
+    // are joined back once: the chains drift apart and the sparse end of one kernel overlaps dense work of others.
     auto launch_all = [&](const RtLaunch &L0, const char **kerr) -> int {
-        if (!wavefront) return rt_launch_render(s->d, L0, nullptr, st, kerr);
-        if (K == 1) return rt_launch_render(s->d, L0, &s->sub[0].ws, st, kerr);
+        auto frame_launch = [&](size_t i, uint32_t parts, uint32_t part) {
+            RtLaunch Li = L0;
+            Li.u = frames[i].u; Li.accum_index = frames[i].accum_index; Li.blend = frames[i].blend ? 1u : 0u;
+            uint32_t rect[4];
+            const bool any = persistent && octree_screen_rect(s->d, frames[i].u, f->width, f->height, rect);
+            hot_tiles(rect, any, f->band_rows, f->band_parts * parts, Li.hot);
+            if (parts > 1) {
+                rt_frame fj = *f;
+                fj.band_parts = f->band_parts * parts; fj.band_part = part * f->band_parts + f->band_part;
+                Li.band_parts = fj.band_parts; Li.band_part = fj.band_part; Li.n_local_rows = band_rows_of(&fj);
+                Li.sub_parts = parts; Li.sub_part = part;
+            }
+            return Li;
+        };
+        if ((!wavefront && !persistent) || K == 1) {
+            for (size_t i = 0; i < n_frames; i++) {
+                const bool wf = wavefront && frames[i].u.max_recursion_limit >= 1;
+                int rc = rt_launch_render(s->d, frame_launch(i, 1, 0), wf ? &s->sub[0].ws : nullptr, (persistent && frames[i].u.max_recursion_limit >= 1) ? s->sub[0].pool : nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr);
+                if (rc != 0) return rc;
+            }
+            return 0;
+        }
         if (hipEventRecord(s->fork_ev, st) != hipSuccess) return 1;
         for (uint32_t j = 0; j < K; j++) {
-            RtLaunch Lj = L0;
-            rt_frame fj = *f;
-            fj.band_parts = f->band_parts * K; fj.band_part = j * f->band_parts + f->band_part;
-            Lj.band_parts = fj.band_parts; Lj.band_part = fj.band_part; Lj.n_local_rows = band_rows_of(&fj);
-            Lj.sub_parts = K; Lj.sub_part = j;
-            if (Lj.n_local_rows == 0) continue;
+            if (frame_launch(0, K, j).n_local_rows == 0) continue;
             if (hipStreamWaitEvent(s->sub[j].stream, s->fork_ev, 0) != hipSuccess) return 1;
-            int rc = rt_launch_render(s->d, Lj, &s->sub[j].ws, s->sub[j].stream, kerr);
-            if (rc != 0) return rc;
+            for (size_t i = 0; i < n_frames; i++) {
+                int rc = rt_launch_render(s->d, frame_launch(i, K, j), (wavefront && frames[i].u.max_recursion_limit >= 1) ? &s->sub[j].ws : nullptr, (persistent && frames[i].u.max_recursion_limit >= 1) ? s->sub[j].pool : nullptr, s->sub[j].stream, kerr, s->timing ? &s->sub[j].probe : nullptr);
+                if (rc != 0) return rc;
+            }
             if (hipEventRecord(s->sub[j].done, s->sub[j].stream) != hipSuccess) return 1;
             if (hipStreamWaitEvent(st, s->sub[j].done, 0) != hipSuccess) return 1;
         }
@@ -404,6 +545,10 @@ int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) {
     return RT_OK;
 }
 
+int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) { return render_frames(s, f, 1, t); }
+
+int rt_render_sequence(rt_scene *s, const rt_frame *frames, size_t n_frames, const rt_target *t) { return render_frames(s, frames, n_frames, t); }
+
 int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     DeviceGuard guard(s->device);
@@ -414,6 +559,8 @@ int rt_scene_destroy(rt_scene *s) {
         if (sb.stream) { (void)hipStreamSynchronize(sb.stream); (void)hipStreamDestroy(sb.stream); }
         if (sb.done) (void)hipEventDestroy(sb.done);
         if (sb.block) (void)hipFree(sb.block);
+        if (sb.pool) (void)hipFree(sb.pool);
+        if (sb.probe.events) { for (uint32_t i = 0; i < 2 * sb.probe.capacity; i++) if (sb.probe.events[i]) (void)hipEventDestroy(sb.probe.events[i]); delete[] sb.probe.events; }
     }
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
     delete s;

@@ -55,6 +55,7 @@ struct RtLaunch {
     uint32_t band_rows, band_parts, band_part, n_local_rows;
     uint32_t compact_rows;
     uint32_t sub_parts, sub_part;   // this launch renders sub-frame sub_part of sub_parts of the caller's band (1, 0: all of it)
+    uint32_t hot[4];                // tile rectangle (x0, y0, x1, y1 inclusive, 16x16 tiles of the local rows) where the octree projects to; x1 < x0: none
     const float *ndc_x, *ndc_y;
     float *color, *depth, *hit_t;
     uint32_t *hit_kind, *hit_slot, *n_rays;
@@ -76,8 +77,18 @@ struct RtWorkspace {
     float4 *prim;          // per-frame (oc.xyz, c) of the 84 spheres for rays starting at the camera
 };
 
+// Optional timing of the dominant kernel (the traversal kernel of the wavefront pipeline, the single kernel of the
+// other): pairs of HIP events recorded on the launch stream directly before and after each such launch.
+struct RtProbe {
+    hipEvent_t *events;   // [2 * capacity]
+    uint32_t capacity;    // pairs
+    uint32_t used;        // pairs recorded so far
+};
+
 // rt_kernels.hip
+size_t rt_pool_bytes();   // size of the persistent path kernel's tile-counter block
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
-// workspace == nullptr: single-kernel pipeline; otherwise the per-depth wavefront pipeline.
-int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, void *stream, const char **err);
+// pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:
+// one-lane-per-pixel kernel; otherwise the per-depth wavefront pipeline.
+int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, uint32_t *pool, void *stream, const char **err, RtProbe *probe = nullptr);

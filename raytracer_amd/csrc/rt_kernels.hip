@@ -165,30 +165,81 @@ __constant__ Material c_materials[7] = {
 };
 #define NUM_SPHERES 84
 // centre xyz + radius; sphere 0 is the ground, 1..80 the small ones (y = r = 0.2), 81..83 the big ones
-__constant__ float4 c_spheres[NUM_SPHERES] = {
-    {0.0f, -1003.0f, 0.0f, 1000.0f},
-    {-7.995381f, 0.2f, -7.478668f, 0.2f}, {-7.696819f, 0.2f, -5.468978f, 0.2f}, {-7.824804f, 0.2f, -3.120637f, 0.2f}, {-7.132909f, 0.2f, -1.701323f, 0.2f},
-    {-7.569523f, 0.2f, 0.494554f, 0.2f},  {-7.730332f, 0.2f, 2.358976f, 0.2f},  {-7.892865f, 0.2f, 4.753728f, 0.2f},  {-7.656691f, 0.2f, 6.888913f, 0.2f},
-    {-7.217835f, 0.2f, 8.203466f, 0.2f},  {-5.115232f, 0.2f, -7.980404f, 0.2f}, {-5.323222f, 0.2f, -5.113037f, 0.2f}, {-5.410681f, 0.2f, -3.527741f, 0.2f},
-    {-5.460670f, 0.2f, -1.166543f, 0.2f}, {-5.457659f, 0.2f, 0.363870f, 0.2f},  {-5.798715f, 0.2f, 2.161684f, 0.2f},  {-5.116586f, 0.2f, 4.470188f, 0.2f},
-    {-5.273591f, 0.2f, 6.795187f, 0.2f},  {-5.120286f, 0.2f, 8.731398f, 0.2f},  {-3.601565f, 0.2f, -7.895600f, 0.2f}, {-3.735860f, 0.2f, -5.163056f, 0.2f},
-    {-3.481116f, 0.2f, -3.794556f, 0.2f}, {-3.866858f, 0.2f, -1.465965f, 0.2f}, {-3.168870f, 0.2f, 0.553099f, 0.2f},  {-3.428552f, 0.2f, 2.627547f, 0.2f},
-    {-3.771736f, 0.2f, 4.324785f, 0.2f},  {-3.768522f, 0.2f, 6.384588f, 0.2f},  {-3.286992f, 0.2f, 8.441148f, 0.2f},  {-1.552127f, 0.2f, -7.728200f, 0.2f},
-    {-1.360796f, 0.2f, -5.346098f, 0.2f}, {-1.287209f, 0.2f, -3.735321f, 0.2f}, {-1.344859f, 0.2f, -1.726654f, 0.2f}, {-1.974774f, 0.2f, 0.183260f, 0.2f},
-    {-1.542872f, 0.2f, 2.067868f, 0.2f},  {-1.743856f, 0.2f, 4.752810f, 0.2f},  {-1.955621f, 0.2f, 6.493702f, 0.2f},  {-1.350449f, 0.2f, 8.068503f, 0.2f},
-    {0.706123f, 0.2f, -7.116040f, 0.2f},  {0.897766f, 0.2f, -5.938681f, 0.2f},  {0.744113f, 0.2f, -3.402960f, 0.2f},  {0.867750f, 0.2f, -1.311908f, 0.2f},
-    {0.082480f, 0.2f, 0.838206f, 0.2f},   {0.649692f, 0.2f, 2.525103f, 0.2f},   {0.378574f, 0.2f, 4.055579f, 0.2f},   {0.425844f, 0.2f, 6.098526f, 0.2f},
-    {0.261365f, 0.2f, 8.661150f, 0.2f},   {2.814218f, 0.2f, -7.751227f, 0.2f},  {2.050073f, 0.2f, -5.731364f, 0.2f},  {2.020130f, 0.2f, -3.472627f, 0.2f},
-    {2.884277f, 0.2f, -1.232662f, 0.2f},  {2.644454f, 0.2f, 0.596324f, 0.2f},   {2.194283f, 0.2f, 2.880603f, 0.2f},   {2.281000f, 0.2f, 4.094307f, 0.2f},
-    {2.080841f, 0.2f, 6.716384f, 0.2f},   {2.287131f, 0.2f, 8.583242f, 0.2f},   {4.329136f, 0.2f, -7.497218f, 0.2f},  {4.502115f, 0.2f, -5.941060f, 0.2f},
-    {4.750631f, 0.2f, -3.836759f, 0.2f},  {4.082084f, 0.2f, -1.180746f, 0.2f},  {4.429173f, 0.2f, 2.069721f, 0.2f},   {4.277152f, 0.2f, 4.297482f, 0.2f},
-    {4.012743f, 0.2f, 6.225072f, 0.2f},   {4.047066f, 0.2f, 8.419360f, 0.2f},   {6.441846f, 0.2f, -7.700798f, 0.2f},  {6.047810f, 0.2f, -5.519369f, 0.2f},
-    {6.779211f, 0.2f, -3.740542f, 0.2f},  {6.430776f, 0.2f, -1.332107f, 0.2f},  {6.476387f, 0.2f, 0.329973f, 0.2f},   {6.568686f, 0.2f, 2.116949f, 0.2f},
-    {6.371189f, 0.2f, 4.609841f, 0.2f},   {6.011877f, 0.2f, 6.569579f, 0.2f},   {6.096087f, 0.2f, 8.892333f, 0.2f},   {8.185763f, 0.2f, -7.191109f, 0.2f},
-    {8.411960f, 0.2f, -5.285309f, 0.2f},  {8.047109f, 0.2f, -3.427552f, 0.2f},  {8.119639f, 0.2f, -1.652587f, 0.2f},  {8.818120f, 0.2f, 0.401292f, 0.2f},
-    {8.754155f, 0.2f, 2.152549f, 0.2f},   {8.595298f, 0.2f, 4.802001f, 0.2f},   {8.036216f, 0.2f, 6.739752f, 0.2f},   {8.256561f, 0.2f, 8.129115f, 0.2f},
+#define SPHERE_TABLE \
+    {0.0f, -1003.0f, 0.0f, 1000.0f}, \
+    {-7.995381f, 0.2f, -7.478668f, 0.2f}, {-7.696819f, 0.2f, -5.468978f, 0.2f}, {-7.824804f, 0.2f, -3.120637f, 0.2f}, {-7.132909f, 0.2f, -1.701323f, 0.2f}, \
+    {-7.569523f, 0.2f, 0.494554f, 0.2f},  {-7.730332f, 0.2f, 2.358976f, 0.2f},  {-7.892865f, 0.2f, 4.753728f, 0.2f},  {-7.656691f, 0.2f, 6.888913f, 0.2f}, \
+    {-7.217835f, 0.2f, 8.203466f, 0.2f},  {-5.115232f, 0.2f, -7.980404f, 0.2f}, {-5.323222f, 0.2f, -5.113037f, 0.2f}, {-5.410681f, 0.2f, -3.527741f, 0.2f}, \
+    {-5.460670f, 0.2f, -1.166543f, 0.2f}, {-5.457659f, 0.2f, 0.363870f, 0.2f},  {-5.798715f, 0.2f, 2.161684f, 0.2f},  {-5.116586f, 0.2f, 4.470188f, 0.2f}, \
+    {-5.273591f, 0.2f, 6.795187f, 0.2f},  {-5.120286f, 0.2f, 8.731398f, 0.2f},  {-3.601565f, 0.2f, -7.895600f, 0.2f}, {-3.735860f, 0.2f, -5.163056f, 0.2f}, \
+    {-3.481116f, 0.2f, -3.794556f, 0.2f}, {-3.866858f, 0.2f, -1.465965f, 0.2f}, {-3.168870f, 0.2f, 0.553099f, 0.2f},  {-3.428552f, 0.2f, 2.627547f, 0.2f}, \
+    {-3.771736f, 0.2f, 4.324785f, 0.2f},  {-3.768522f, 0.2f, 6.384588f, 0.2f},  {-3.286992f, 0.2f, 8.441148f, 0.2f},  {-1.552127f, 0.2f, -7.728200f, 0.2f}, \
+    {-1.360796f, 0.2f, -5.346098f, 0.2f}, {-1.287209f, 0.2f, -3.735321f, 0.2f}, {-1.344859f, 0.2f, -1.726654f, 0.2f}, {-1.974774f, 0.2f, 0.183260f, 0.2f}, \
+    {-1.542872f, 0.2f, 2.067868f, 0.2f},  {-1.743856f, 0.2f, 4.752810f, 0.2f},  {-1.955621f, 0.2f, 6.493702f, 0.2f},  {-1.350449f, 0.2f, 8.068503f, 0.2f}, \
+    {0.706123f, 0.2f, -7.116040f, 0.2f},  {0.897766f, 0.2f, -5.938681f, 0.2f},  {0.744113f, 0.2f, -3.402960f, 0.2f},  {0.867750f, 0.2f, -1.311908f, 0.2f}, \
+    {0.082480f, 0.2f, 0.838206f, 0.2f},   {0.649692f, 0.2f, 2.525103f, 0.2f},   {0.378574f, 0.2f, 4.055579f, 0.2f},   {0.425844f, 0.2f, 6.098526f, 0.2f}, \
+    {0.261365f, 0.2f, 8.661150f, 0.2f},   {2.814218f, 0.2f, -7.751227f, 0.2f},  {2.050073f, 0.2f, -5.731364f, 0.2f},  {2.020130f, 0.2f, -3.472627f, 0.2f}, \
+    {2.884277f, 0.2f, -1.232662f, 0.2f},  {2.644454f, 0.2f, 0.596324f, 0.2f},   {2.194283f, 0.2f, 2.880603f, 0.2f},   {2.281000f, 0.2f, 4.094307f, 0.2f}, \
+    {2.080841f, 0.2f, 6.716384f, 0.2f},   {2.287131f, 0.2f, 8.583242f, 0.2f},   {4.329136f, 0.2f, -7.497218f, 0.2f},  {4.502115f, 0.2f, -5.941060f, 0.2f}, \
+    {4.750631f, 0.2f, -3.836759f, 0.2f},  {4.082084f, 0.2f, -1.180746f, 0.2f},  {4.429173f, 0.2f, 2.069721f, 0.2f},   {4.277152f, 0.2f, 4.297482f, 0.2f}, \
+    {4.012743f, 0.2f, 6.225072f, 0.2f},   {4.047066f, 0.2f, 8.419360f, 0.2f},   {6.441846f, 0.2f, -7.700798f, 0.2f},  {6.047810f, 0.2f, -5.519369f, 0.2f}, \
+    {6.779211f, 0.2f, -3.740542f, 0.2f},  {6.430776f, 0.2f, -1.332107f, 0.2f},  {6.476387f, 0.2f, 0.329973f, 0.2f},   {6.568686f, 0.2f, 2.116949f, 0.2f}, \
+    {6.371189f, 0.2f, 4.609841f, 0.2f},   {6.011877f, 0.2f, 6.569579f, 0.2f},   {6.096087f, 0.2f, 8.892333f, 0.2f},   {8.185763f, 0.2f, -7.191109f, 0.2f}, \
+    {8.411960f, 0.2f, -5.285309f, 0.2f},  {8.047109f, 0.2f, -3.427552f, 0.2f},  {8.119639f, 0.2f, -1.652587f, 0.2f},  {8.818120f, 0.2f, 0.401292f, 0.2f}, \
+    {8.754155f, 0.2f, 2.152549f, 0.2f},   {8.595298f, 0.2f, 4.802001f, 0.2f},   {8.036216f, 0.2f, 6.739752f, 0.2f},   {8.256561f, 0.2f, 8.129115f, 0.2f}, \
     {0.0f, 2.0f, 0.0f, 1.0f}, {-4.0f, 2.0f, 0.0f, 1.0f}, {4.0f, 2.0f, 0.0f, 1.0f},
+__constant__ float4 c_spheres[NUM_SPHERES] = {SPHERE_TABLE};
+
+// Culling structure over the sphere table, built at compile time.  Spheres of radius <= SG_SMALL_RADIUS are binned by
+// their footprint, dilated by SG_DILATE on every side, into a grid of SG_CELL x SG_CELL cells over x and z; they all
+// lie between two horizontal planes (again dilated).  A ray can only be accepted by the sphere test for such a sphere
+// if it passes within radius + (rounding slack) of the centre, and for ray origins within SG_ORIGIN_LIMIT of the world
+// origin the rounding slack of the float test (frag:233-252) stays far below SG_DILATE: the discriminant b*b - c
+// carries an absolute error below 1e-2 there, while dilating a 0.2 sphere by 0.05 moves it by 2.2e-2.  So testing
+// only the spheres binned into the cells that the ray crosses inside the slab (plus every larger sphere), in index
+// order, gives exactly the result of the full loop; rays that start farther out take the full loop.
+#define SG_CELL 2.0f
+#define SG_MAX 12
+#define SG_DILATE 0.05f
+#define SG_SMALL_RADIUS 0.5f
+#define SG_ORIGIN_LIMIT 32.0f
+struct SphereGrid {
+    float x0, x1, y0, y1, z0, z1;    // dilated bounds of the binned spheres
+    int32_t nx, nz;
+    uint32_t always[3];              // spheres every ray tests (not binned)
+    uint32_t cell[SG_MAX * SG_MAX][3];
 };
+constexpr int sg_floor(float v) { const int i = (int)v; return (float)i > v ? i - 1 : i; }
+constexpr SphereGrid make_sphere_grid() {
+    constexpr float tab[NUM_SPHERES][4] = {SPHERE_TABLE};
+    SphereGrid g = {};
+    bool any = false;
+    for (int i = 0; i < NUM_SPHERES; i++) {
+        const float r = tab[i][3] + SG_DILATE;
+        if (tab[i][3] > SG_SMALL_RADIUS) { g.always[i >> 5] |= 1u << (i & 31); continue; }
+        const float lo[3] = {tab[i][0] - r, tab[i][1] - r, tab[i][2] - r}, hi[3] = {tab[i][0] + r, tab[i][1] + r, tab[i][2] + r};
+        if (!any) { g.x0 = lo[0]; g.x1 = hi[0]; g.y0 = lo[1]; g.y1 = hi[1]; g.z0 = lo[2]; g.z1 = hi[2]; any = true; }
+        g.x0 = lo[0] < g.x0 ? lo[0] : g.x0; g.x1 = hi[0] > g.x1 ? hi[0] : g.x1;
+        g.y0 = lo[1] < g.y0 ? lo[1] : g.y0; g.y1 = hi[1] > g.y1 ? hi[1] : g.y1;
+        g.z0 = lo[2] < g.z0 ? lo[2] : g.z0; g.z1 = hi[2] > g.z1 ? hi[2] : g.z1;
+    }
+    g.nx = sg_floor((g.x1 - g.x0) / SG_CELL) + 1;
+    g.nz = sg_floor((g.z1 - g.z0) / SG_CELL) + 1;
+    const bool fits = g.nx <= SG_MAX && g.nz <= SG_MAX;
+    for (int i = 0; i < NUM_SPHERES; i++) {
+        if (tab[i][3] > SG_SMALL_RADIUS) continue;
+        if (!fits) { g.always[i >> 5] |= 1u << (i & 31); continue; }   // table too wide for the grid: no culling
+        const float r = tab[i][3] + SG_DILATE;
+        const int xa = sg_floor((tab[i][0] - r - g.x0) / SG_CELL), xb = sg_floor((tab[i][0] + r - g.x0) / SG_CELL);
+        const int za = sg_floor((tab[i][2] - r - g.z0) / SG_CELL), zb = sg_floor((tab[i][2] + r - g.z0) / SG_CELL);
+        for (int x = xa < 0 ? 0 : xa; x <= xb && x < g.nx; x++)
+            for (int z = za < 0 ? 0 : za; z <= zb && z < g.nz; z++) g.cell[x * SG_MAX + z][i >> 5] |= 1u << (i & 31);
+    }
+    if (!fits) { g.nx = 0; g.nz = 0; }
+    return g;
+}
+__constant__ SphereGrid c_sphere_grid = make_sphere_grid();
+
 
 
 // ------------------------------------------------------------------------------------------------
@@ -222,15 +273,78 @@ DEVI void sphere_accept(float b, float c, uint32_t i, float &closest, uint32_t &
     const float t = t1 < 0.0f ? t2 : t1;
     if (t < closest && t > 0.0f) { closest = t; closest_i = i; }
 }
-// The 84 sphere records are read from a workgroup-shared LDS copy (every lane reads the same address: a broadcast),
-// whose loads the compiler can keep in flight ahead of the arithmetic; scalar loads from constant memory cannot be
-// waited for individually and stalled every group of spheres.
-DEVI void stage_sphere_table(float4 *lds_tab, const float4 *src) {
-    if (threadIdx.x < NUM_SPHERES) lds_tab[threadIdx.x] = src[threadIdx.x];
+// The sphere records are read from a workgroup-shared LDS copy: loads the compiler can keep in flight ahead of the
+// arithmetic, whereas scalar loads from constant memory cannot be waited for individually.
+struct SphereLds { float4 tab[NUM_SPHERES]; SphereGrid grid; };
+DEVI void stage_spheres(SphereLds *lds, const float4 *src) {
+    if (threadIdx.x < NUM_SPHERES) lds->tab[threadIdx.x] = src[threadIdx.x];
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&lds->grid);
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(&c_sphere_grid);
+    for (uint32_t i = threadIdx.x; i < sizeof(SphereGrid) / 4u; i += blockDim.x) dst[i] = g[i];
     __syncthreads();
 }
+// Set of spheres that the ray can possibly be accepted by (a superset is always correct).
+struct SphereMask { uint32_t w[3]; };
+DEVI SphereMask sphere_candidates(const SphereGrid *g, const Ray &r) {
+    SphereMask m = {{g->always[0], g->always[1], g->always[2]}};
+    const SphereMask all = {{0xFFFFFFFFu, 0xFFFFFFFFu, (1u << (NUM_SPHERES - 64)) - 1u}};
+    if (g->nx == 0) return m;
+    const float far = fmaxf(fmaxf(fabsf(r.pos.x), fabsf(r.pos.y)), fabsf(r.pos.z));
+    if (!(far <= SG_ORIGIN_LIMIT)) return all;
+    // part of the ray inside the slab of the binned spheres (a NaN from 0 * inf drops out of min/max)
+    const float tx1 = (g->x0 - r.pos.x) * r.inv.x, tx2 = (g->x1 - r.pos.x) * r.inv.x;
+    const float ty1 = (g->y0 - r.pos.y) * r.inv.y, ty2 = (g->y1 - r.pos.y) * r.inv.y;
+    const float tz1 = (g->z0 - r.pos.z) * r.inv.z, tz2 = (g->z1 - r.pos.z) * r.inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), 0.0f));
+    const float t1 = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+    if (!(t1 < 1e30f)) return all;     // not a proper ray (NaN or zero direction): no culling
+    if (!(t0 <= t1)) return m;
+    const float ax = r.pos.x + r.dir.x * t0, bx = r.pos.x + r.dir.x * t1;
+    const float az = r.pos.z + r.dir.z * t0, bz = r.pos.z + r.dir.z * t1;
+    const float ic = 1.0f / SG_CELL, slack = 1e-3f;
+    const int nx1 = g->nx - 1, nz1 = g->nz - 1;
+    const int ixa = min(max((int)floorf((fminf(ax, bx) - g->x0) * ic - slack), 0), nx1);
+    const int ixb = min(max((int)floorf((fmaxf(ax, bx) - g->x0) * ic + slack), 0), nx1);
+    for (int ix = ixa; ix <= ixb; ix++) {
+        float za = az, zb = bz;
+        if (ixa != ixb) {   // the ray's stretch inside this column of cells
+            const float xl = g->x0 + SG_CELL * (float)ix - 2.0f * slack, xr = xl + SG_CELL + 4.0f * slack;
+            const float ta = (xl - r.pos.x) * r.inv.x, tb = (xr - r.pos.x) * r.inv.x;
+            const float ts = fminf(fmaxf(fminf(ta, tb), t0), t1), te = fmaxf(fminf(fmaxf(ta, tb), t1), t0);
+            za = r.pos.z + r.dir.z * ts; zb = r.pos.z + r.dir.z * te;
+        }
+        const int iza = min(max((int)floorf((fminf(za, zb) - g->z0) * ic - slack), 0), nz1);
+        const int izb = min(max((int)floorf((fmaxf(za, zb) - g->z0) * ic + slack), 0), nz1);
+        for (int iz = iza; iz <= izb; iz++) {
+            const uint32_t *c = g->cell[ix * SG_MAX + iz];
+            m.w[0] |= c[0]; m.w[1] |= c[1]; m.w[2] |= c[2];
+        }
+    }
+    return m;
+}
+// The sphere loop of frag:439-445 over the candidate set, in index order.  PRIMARY: tab holds (oc.xyz, c) of a shared
+// ray origin; otherwise (centre.xyz, radius).
+template <bool PRIMARY>
+DEVI void intersect_spheres_culled(const SphereLds *lds, const Ray &r, float &closest, uint32_t &closest_i) {
+    const SphereMask m = sphere_candidates(&lds->grid, r);
+#pragma unroll
+    for (uint32_t w = 0; w < 3; w++) {
+        uint32_t bits = m.w[w];
+        while (bits) {
+            const uint32_t i = w * 32u + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            const float4 s = lds->tab[i];
+            if (PRIMARY) {
+                sphere_accept(dot3(F3(s.x, s.y, s.z), r.dir), s.w, i, closest, closest_i);
+            } else {
+                const f3 oc = r.pos - F3(s.x, s.y, s.z);
+                sphere_accept(dot3(oc, r.dir), dot3(oc, oc) - s.w * s.w, i, closest, closest_i);
+            }
+        }
+    }
+}
 // Generic origin: lds_tab holds (centre.xyz, radius).
-DEVI void intersect_spheres(const float4 *lds_tab, const Ray &r, float &closest, uint32_t &closest_i) {
+[[maybe_unused]] DEVI void intersect_spheres(const float4 *lds_tab, const Ray &r, float &closest, uint32_t &closest_i) {
 #pragma unroll 6
     for (uint32_t i = 0; i < NUM_SPHERES; i++) {
         const float4 s = lds_tab[i];
@@ -242,7 +356,7 @@ DEVI void intersect_spheres(const float4 *lds_tab, const Ray &r, float &closest,
 }
 // Primary rays share their origin, so oc and c are per-frame constants of each sphere: lds_tab holds (oc.xyz, c)
 // computed once with the very same operations.
-DEVI void intersect_spheres_primary(const float4 *lds_tab, f3 dir, float &closest, uint32_t &closest_i) {
+[[maybe_unused]] DEVI void intersect_spheres_primary(const float4 *lds_tab, f3 dir, float &closest, uint32_t &closest_i) {
 #pragma unroll 6
     for (uint32_t i = 0; i < NUM_SPHERES; i++) {
         const float4 s = lds_tab[i];
@@ -651,12 +765,8 @@ DEVI void write_pixel(const RtLaunch &L, size_t pi, f3 c) {
 // workgroups are renumbered so that the 8 round-robin dispatch classes (blockIdx % 8: the workgroups that share an
 // XCD's L2) each own a contiguous range of tiles.
 struct PixelId { uint32_t x, y, lr; bool active; size_t fi, pi; };
-DEVI PixelId pixel_of(const RtLaunch &L, uint32_t bid_raw, uint32_t tid) {
-    const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
-    const uint32_t nwg = tiles_x * tiles_y;
-    const uint32_t q = nwg / 8u, rem = nwg % 8u, cls = bid_raw % 8u, idx = bid_raw / 8u;
-    const uint32_t bid = (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;   // bijective
-    const uint32_t tile_x = bid % tiles_x, tile_y = bid / tiles_x;
+// Pixel `tid` (0..255: four 8x8 quarters of 64) of the 16x16 tile at (tile_x, tile_y) of this launch's local rows.
+DEVI PixelId pixel_of_tile(const RtLaunch &L, uint32_t tile_x, uint32_t tile_y, uint32_t tid) {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     PixelId p;
     p.x = tile_x * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -670,6 +780,33 @@ DEVI PixelId pixel_of(const RtLaunch &L, uint32_t bid_raw, uint32_t tid) {
     const uint32_t part_lr = ((p.lr / L.band_rows) * L.sub_parts + L.sub_part) * L.band_rows + (p.lr % L.band_rows);
     p.pi = L.compact_rows ? (size_t)part_lr * L.width + p.x : p.fi;
     return p;
+}
+DEVI PixelId pixel_of(const RtLaunch &L, uint32_t bid_raw, uint32_t tid) {
+    const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
+    const uint32_t nwg = tiles_x * tiles_y;
+    const uint32_t q = nwg / 8u, rem = nwg % 8u, cls = bid_raw % 8u, idx = bid_raw / 8u;
+    const uint32_t bid = (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;   // bijective
+    return pixel_of_tile(L, bid % tiles_x, bid / tiles_x, tid);
+}
+// Tile order of the persistent path kernel: the tiles of the rectangle L.hot (where the octree projects to: the
+// pixels whose paths can be long) come first, then the rows below it, the rows above it, and the tiles left and right
+// of it, so that the expensive paths start early and the frame ends on cheap ones.  k -> (tile_x, tile_y), bijective.
+DEVI void path_tile(const RtLaunch &L, uint32_t k, uint32_t &tile_x, uint32_t &tile_y) {
+    const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
+    const uint32_t tx0 = L.hot[0], ty0 = L.hot[1], tx1 = min(L.hot[2], tiles_x - 1u), ty1 = min(L.hot[3], tiles_y - 1u);
+    if (tx1 < tx0 || ty1 < ty0) { tile_x = k % tiles_x; tile_y = k / tiles_x; return; }
+    const uint32_t w = tx1 - tx0 + 1u, h = ty1 - ty0 + 1u;
+    if (k < w * h) { tile_x = tx0 + k % w; tile_y = ty0 + k / w; return; }
+    k -= w * h;
+    if (k < ty0 * tiles_x) { tile_x = k % tiles_x; tile_y = k / tiles_x; return; }
+    k -= ty0 * tiles_x;
+    const uint32_t above = (tiles_y - 1u - ty1) * tiles_x;
+    if (k < above) { tile_x = k % tiles_x; tile_y = ty1 + 1u + k / tiles_x; return; }
+    k -= above;
+    const uint32_t side = tiles_x - w;   // > 0 here: otherwise the three cases above cover every tile
+    const uint32_t c = k % side;
+    tile_x = c < tx0 ? c : c + w;
+    tile_y = ty0 + k / side;
 }
 DEVI void pixel_ndc(const RtLaunch &L, const PixelId &p, float &nx, float &ny) {
     nx = L.ndc_x ? L.ndc_x[p.fi] : div_ieee(2.0f * ((float)p.x + 0.5f), (float)L.width) - 1.0f;
@@ -689,14 +826,20 @@ DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
     }
 }
 
+#ifdef RT_FULL_SPHERE_LOOP   // A/B switch: test all 84 spheres for every ray
+#define SPHERE_LOOP(PRIMARY, lds, ray, closest, closest_i) do { if (PRIMARY) intersect_spheres_primary((lds).tab, (ray).dir, closest, closest_i); else intersect_spheres((lds).tab, ray, closest, closest_i); } while (0)
+#else
+#define SPHERE_LOOP(PRIMARY, lds, ray, closest, closest_i) intersect_spheres_culled<PRIMARY>(&(lds), ray, closest, closest_i)
+#endif
+
 // ================================================================================================
 // Pipeline 1: one kernel, one lane per pixel for the whole path (kept as the simple cross-check).
 // ================================================================================================
 template <int LEVELS, bool COUNT>
 __global__ __launch_bounds__(256) void render_kernel(RtDeviceScene S, RtLaunch L) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
-    __shared__ float4 lds_sph[NUM_SPHERES];
-    stage_sphere_table(lds_sph, c_spheres);
+    __shared__ SphereLds lds_sph;
+    stage_spheres(&lds_sph, c_spheres);
     LevelStack st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
@@ -720,7 +863,7 @@ __global__ __launch_bounds__(256) void render_kernel(RtDeviceScene S, RtLaunch L
             uint32_t closest_i = 0, closest_tri = 0;
             bool tri_hit = false;
             if (COUNT) cn.rays++;
-            intersect_spheres(lds_sph, ray, closest, closest_i);
+            SPHERE_LOOP(false, lds_sph, ray, closest, closest_i);
             if (root_box_test(S, ray, closest)) {
                 if (COUNT) cn.entered++;
                 st.reset_to_root();
@@ -799,8 +942,8 @@ template <bool D0>
 __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles) {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t lds_base;
-    __shared__ float4 lds_sph[NUM_SPHERES];
-    stage_sphere_table(lds_sph, D0 ? WS.prim : c_spheres);
+    __shared__ SphereLds lds_sph;
+    stage_spheres(&lds_sph, D0 ? WS.prim : c_spheres);
     const uint32_t cur = depth & 1u;
     float4 *__restrict__ A = WS.pos_seed[cur];
     float4 *__restrict__ B = WS.dir_pix[cur];
@@ -829,7 +972,7 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
             WS.color[cur][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
             if (valid) {
                 ray.inv = rcp3(ray.dir);
-                intersect_spheres_primary(lds_sph, ray.dir, closest, closest_i);
+                SPHERE_LOOP(true, lds_sph, ray, closest, closest_i);
                 enter = root_box_test(S, ray, closest);
             }
         } else if (valid) {
@@ -837,7 +980,7 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
             ray.pos = F3(a.x, a.y, a.z);
             ray.dir = F3(b.x, b.y, b.z);
             ray.inv = rcp3(ray.dir);
-            intersect_spheres(lds_sph, ray, closest, closest_i);
+            SPHERE_LOOP(false, lds_sph, ray, closest, closest_i);
             enter = root_box_test(S, ray, closest);
         }
         if (D0 || valid) {
@@ -996,6 +1139,177 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
     if (COUNT && L.counters) flush_counters(L.counters, cn);
 }
 
+
+// ================================================================================================
+// Pipeline 3: persistent path kernel.  A fixed number of waves stays resident for the whole frame; every lane carries
+// one path at a time and is in one of two phases: traversing the octree (a stack is live), or waiting for the
+// "segment block" -- hit assembly, scattering or sky, pixel write when the path ends, a new pixel from the wave's
+// supply when the lane is free, then the sphere loop and the root box test of the next segment.  A wave runs the
+// segment block for all waiting lanes together once PATH_REFILL of them wait (or none traverses), and otherwise
+// advances the traversing lanes node by node, so neither phase executes with a nearly empty wave and the serial
+// chain of one long ray overlaps everything else the machine does.  Pixels are handed out in 8x8 tiles: a wave's
+// tiles come from global counters (one atomic per 64 pixels, spread over PATH_POOLS counters).
+// ================================================================================================
+#ifndef PATH_REFILL
+#define PATH_REFILL 16         // waiting lanes that trigger the segment block while others still traverse
+#endif
+#ifndef PATH_MIN_VISITS
+#define PATH_MIN_VISITS 4      // node visits the traversing lanes get between two segment blocks
+#endif
+#define PATH_POOLS 64u         // tile counters (atomics on one address serialise at several ns each: spread them)
+#define PATH_POOL_STRIDE 64u   // words between two counters: one per 256-byte line
+#ifndef PATH_TAIL_VISITS
+#define PATH_TAIL_VISITS 16    // the same once the wave's pixel supply is dry (any waiting lane then triggers a block)
+#endif
+#ifndef PATH_WG_PER_CU
+#define PATH_WG_PER_CU 3       // resident workgroups per CU (register-limited)
+#endif
+
+#ifndef PATH_WAVES_PER_SIMD
+#define PATH_WAVES_PER_SIMD 3
+#endif
+template <int LEVELS, bool COUNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATH_WAVES_PER_SIMD, PATH_WAVES_PER_SIMD))) void path_kernel(RtDeviceScene S, RtLaunch L, uint32_t *pool, uint32_t n_tiles) {
+    __shared__ uint32_t lds_stack[LEVELS * 256];
+    __shared__ SphereLds lds_sph;
+    stage_spheres(&lds_sph, c_spheres);
+    LevelStack st;
+    st.col = &lds_stack[threadIdx.x];
+    st.sp = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t n_units = n_tiles * 4u;   // unit = 8x8 pixels = quarter of a 16x16 tile
+    const uint32_t limit = L.u.max_recursion_limit;
+    // Wave-uniform pixel supply.  Counter c hands out the units c, c + PATH_POOLS, c + 2 PATH_POOLS, ...; a wave draws
+    // from its home counter and moves on to the next one when that runs dry, until all of them have.
+    uint32_t home = (blockIdx.x * 4u + (threadIdx.x >> 6)) % PATH_POOLS, dry = 0;
+    auto next_unit = [&]() -> uint32_t {
+        while (dry < PATH_POOLS) {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(&pool[home * PATH_POOL_STRIDE], 1u);
+            const uint32_t u = __shfl(k, 0, 64) * PATH_POOLS + home;
+            if (u < n_units) return u;
+            home = (home + 1u) % PATH_POOLS;
+            dry++;
+        }
+        return 0xFFFFFFFFu;
+    };
+#ifdef PATH_TRACE
+    const unsigned long long t_start = wall_clock64();
+#endif
+    uint32_t unit = limit > 0 ? next_unit() : 0xFFFFFFFFu, cursor = 0;   // `cursor` pixels of `unit` are handed out
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    bool has_path = false, traversing = false, tri_hit = false;
+    uint32_t pix = 0, seg = 0, closest_i = 0, closest_tri = 0;
+    float closest = 0.0f;
+    Ray ray;
+    ray.pos = ray.dir = ray.inv = F3(0.0f, 0.0f, 0.0f);
+    f3 color = F3(1.0f, 1.0f, 1.0f);
+    Seed seed;
+    seed.base = 0.0f; seed.k = 0;
+    for (;;) {
+        const unsigned long long trav = __ballot(traversing);
+        const unsigned long long work = __ballot(!traversing && (has_path || (unit < n_units && limit > 0)));
+        if (trav == 0 && work == 0) break;
+        // once the wave's pixel supply is dry only latency matters: any waiting lane gets the block at once
+        const uint32_t refill = unit < n_units ? PATH_REFILL : 1u;
+        if (work != 0 && (trav == 0 || (uint32_t)__popcll(work) >= refill)) {
+            if (has_path && !traversing) {   // the segment's intersection is complete (frag:535-563,575-664)
+                PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
+                const Hit h = finish_intersection<COUNT>(S, L.u, ray, closest, closest_i, closest_tri, tri_hit, seg == 0 ? &tap : nullptr, cn);
+                if (seg == 0) {
+                    if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
+                    if (L.hit_kind) L.hit_kind[pix] = tap.kind;
+                    if (L.hit_slot) L.hit_slot[pix] = tap.slot;
+                    if (L.hit_t) L.hit_t[pix] = tap.t;
+                }
+                seg++;
+                bool done;
+                if (!h.has_hit) {
+                    color = color * sample_sky(S, ray.dir);
+                    done = true;
+                } else {
+                    scatter(L.u, h, ray, color, seed);
+                    ray.inv = rcp3(ray.dir);
+                    done = seg >= limit;
+                }
+                if (done) {
+                    write_pixel(L, pix, tonemap(color));
+                    if (L.n_rays) L.n_rays[pix] = seg;
+                    has_path = false;
+                }
+            }
+            const unsigned long long need = __ballot(!has_path);
+            bool fresh = false;
+            if (need != 0 && unit < n_units && limit > 0) {   // wave-uniform
+                uint32_t tile_x, tile_y;
+                path_tile(L, unit >> 2, tile_x, tile_y);
+                const uint32_t n_take = min((uint32_t)__popcll(need), 64u - cursor);
+                const uint32_t rank = (uint32_t)__popcll(need & lt_mask);
+                if (!has_path && rank < n_take) {
+                    const PixelId p = pixel_of_tile(L, tile_x, tile_y, (unit & 3u) * 64u + cursor + rank);
+                    if (p.active) {
+                        float nx, ny;
+                        pixel_ndc(L, p, nx, ny);
+                        ray.pos = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]);
+                        generate_ray(L.u, nx, ny, ray.dir, seed.base);
+                        seed.k = 0;
+                        ray.inv = rcp3(ray.dir);
+                        color = F3(1.0f, 1.0f, 1.0f);
+                        pix = (uint32_t)p.pi;
+                        seg = 0;
+                        has_path = true;
+                        fresh = true;
+                    }
+                }
+                cursor += n_take;
+                if (cursor == 64u) {
+                    cursor = 0;
+                    unit = next_unit();
+                }
+            }
+            (void)fresh;
+            if (has_path && !traversing) {   // next segment: spheres, then the octree if its root box is hit (frag:437-453)
+                closest = __builtin_inff();
+                closest_i = 0; closest_tri = 0; tri_hit = false;
+                if (COUNT) cn.rays++;
+                SPHERE_LOOP(false, lds_sph, ray, closest, closest_i);
+                if (root_box_test(S, ray, closest)) {
+                    if (COUNT) cn.entered++;
+                    st.reset_to_root();
+                    traversing = true;
+                }
+            }
+        }
+        for (uint32_t steps = 0;; steps++) {
+            const unsigned long long t = __ballot(traversing);
+            if (t == 0) break;
+            if (steps >= (unit < n_units ? PATH_MIN_VISITS : PATH_TAIL_VISITS)) {
+                const unsigned long long w = __ballot(!traversing && (has_path || unit < n_units));
+                if ((uint32_t)__popcll(w) >= (unit < n_units ? PATH_REFILL : 1u)) break;
+            }
+            if (traversing) {
+                visit_node<COUNT>(S, ray, st, closest, closest_tri, tri_hit, cn);
+                if (st.empty()) traversing = false;
+            }
+        }
+    }
+#ifdef PATH_TRACE   // development aid: per-wave start / end wall clock behind the counters
+    if (lane == 0) {
+        const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(pool + PATH_POOLS * PATH_POOL_STRIDE);
+        tr[2 * w] = t_start; tr[2 * w + 1] = wall_clock64();
+    }
+#endif
+    if (COUNT && L.counters) flush_counters(L.counters, cn);
+}
+
+template <int LEVELS>
+void launch_path(const RtDeviceScene &S, const RtLaunch &L, uint32_t *pool, uint32_t n_tiles, hipStream_t st, dim3 grid) {
+    if (L.counters) hipLaunchKernelGGL((path_kernel<LEVELS, true>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
+    else hipLaunchKernelGGL((path_kernel<LEVELS, false>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
+}
+
 template <int LEVELS>
 int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid) {
     if (L.counters) hipLaunchKernelGGL((render_kernel<LEVELS, true>), grid, dim3(256), 0, st, S, L);
@@ -1011,13 +1325,18 @@ void launch_traverse(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
 
 }  // namespace
 
+#ifdef PATH_TRACE
+size_t rt_pool_bytes() { return (size_t)PATH_POOLS * PATH_POOL_STRIDE * sizeof(uint32_t) + 16384 * 16; }
+#else
+size_t rt_pool_bytes() { return (size_t)PATH_POOLS * PATH_POOL_STRIDE * sizeof(uint32_t); }
+#endif
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows) {
     const size_t n_tiles = (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u);
     return (n_tiles + RANGE / 256u - 1) / (RANGE / 256u);
 }
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows) { return rt_workspace_ranges(width, n_local_rows) * RANGE; }
 
-int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace *WS, void *stream, const char **err) {
+int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe) {
     const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
     if (tiles_x == 0 || tiles_y == 0) return 0;
     const uint32_t n_tiles = tiles_x * tiles_y;
@@ -1025,11 +1344,33 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
     // the traversal stack holds at most one entry per tree level (the root's virtual level included)
     const uint32_t need = S.max_depth + 2u;
     int rc = 0;
-    if (!WS) {
+    const bool timed = probe && probe->used < probe->capacity;
+    auto mark = [&](uint32_t which) { if (timed) (void)hipEventRecord(probe->events[2 * probe->used + which], st); };
+    if (pool) {
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            n_cu = v;
+        }
+        const uint32_t n_units = n_tiles * 4u;
+        const uint32_t wgs = min((uint32_t)n_cu * PATH_WG_PER_CU, (n_units + 3u) / 4u);
+        (void)hipMemsetAsync(pool, 0, rt_pool_bytes(), st);
+        mark(0);
+        if (need <= 12) launch_path<12>(S, L, pool, n_tiles, st, dim3(wgs));
+        else if (need <= 20) launch_path<20>(S, L, pool, n_tiles, st, dim3(wgs));
+        else launch_path<RT_MAX_TREE_DEPTH + 2>(S, L, pool, n_tiles, st, dim3(wgs));
+        mark(1);
+        if (timed) probe->used++;
+        rc = (int)hipGetLastError();
+    } else if (!WS) {
         const dim3 grid(n_tiles);
+        mark(0);
         if (need <= 12) rc = launch_megakernel<12>(S, L, st, grid);
         else if (need <= 20) rc = launch_megakernel<20>(S, L, st, grid);
         else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid);
+        mark(1);
+        if (timed) probe->used++;
     } else {
         const bool count = L.counters != nullptr;
         const dim3 grid((uint32_t)rt_workspace_ranges(L.width, L.n_local_rows));   // one workgroup per slot range
@@ -1044,9 +1385,12 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
             if (d == 0) hipLaunchKernelGGL((spheres_kernel<true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
             else hipLaunchKernelGGL((spheres_kernel<false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
             if (S.n_nodes) {
+                const bool t = timed && probe->used < probe->capacity;
+                if (t) mark(0);
                 if (need <= 12) launch_traverse<12>(S, L, *WS, d, st, tgrid);
                 else if (need <= 20) launch_traverse<20>(S, L, *WS, d, st, tgrid);
                 else launch_traverse<RT_MAX_TREE_DEPTH + 2>(S, L, *WS, d, st, tgrid);
+                if (t) { mark(1); probe->used++; }
             }
             const uint32_t track = ask ? 1u : 0u;
             if (d == 0) {

@@ -54,7 +54,7 @@ VIEWS = {
 }
 
 
-@pytest.fixture(scope="module", params=["wavefront", "megakernel"])
+@pytest.fixture(scope="module", params=["wavefront", "megakernel", "persistent"])
 def bunny_pair(request, bunny_octree, test_sky):
     from oracle import oracle
     sc = api.Scene.from_octree(bunny_octree)
@@ -144,14 +144,15 @@ def test_subframes_and_pipelines_identical_large_frame(bunny_octree, test_sky):
     u = Uniforms.from_camera(Camera(aspect=w / h), max_recursion_limit=3).pack()
     sc.set_pipeline("megakernel")
     ref = sc.render(u, w, h)
-    sc.set_pipeline("wavefront")
-    for n in (1, 2, 4, 7):
+    for pipe, n in [("wavefront", n) for n in (1, 2, 4, 7)] + [("persistent", n) for n in (1, 3)]:
+        sc.set_pipeline(pipe)
         sc.set_subframes(n)
         g = sc.render(u, w, h)
         for k in ("rgba", "depth", "t"):
-            assert np.array_equal(bits(g[k]), bits(ref[k])), (n, k)
+            assert np.array_equal(bits(g[k]), bits(ref[k])), (pipe, n, k)
         for k in ("kind", "slot", "nrays"):
-            assert np.array_equal(g[k], ref[k]), (n, k)
+            assert np.array_equal(g[k], ref[k]), (pipe, n, k)
+    sc.set_pipeline("wavefront")
     # compact band buffers of 2 parts re-interleave to the same frame
     from raytracer_amd import dist as rdist
     sc.set_subframes(4)
@@ -166,4 +167,66 @@ def test_subframes_and_pipelines_identical_large_frame(bunny_octree, test_sky):
         ys = rdist.local_to_frame_rows(h, 16, 2, part)
         frame[ys[ys >= 0]] = buf[ys >= 0]
     assert np.array_equal(bits(frame), bits(ref["rgba"]))
+    sc.close()
+
+
+def test_render_sequence_equals_frame_by_frame(bunny_octree, test_sky):
+    """rt_render_sequence (sub-frame chains pipelined across frames) accumulates to the same bits as one rt_render
+    per frame, for every pipeline / sub-frame count, with per-frame uniforms (time advances) and a host target."""
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(test_sky)
+    w, h = 2048, 1080
+    n = 4
+    us = [Uniforms.from_camera(Camera(aspect=w / h), time=k / 60.0, max_recursion_limit=2 + (k & 1)).pack() for k in range(n)]
+    sc.set_pipeline("megakernel")
+    ref = np.zeros((h, w, 4), np.float32)
+    for k in range(n):
+        ref = sc.render(us[k], w, h, accum_index=k + 1, color=ref, planes=False)["rgba"]
+    for pipe, sub in (("megakernel", 1), ("wavefront", 1), ("wavefront", 2), ("wavefront", 4), ("persistent", 1), ("persistent", 3)):
+        sc.set_pipeline(pipe)
+        sc.set_subframes(sub)
+        buf = np.zeros((h, w, 4), np.float32)
+        depth = np.zeros((h, w), np.float32)
+        tg = api.rt_target()
+        tg.memory, tg.sync, tg.color, tg.depth = api.RT_MEM_HOST, 1, buf.ctypes.data, depth.ctypes.data
+        sc.render_sequence_raw([api.make_frame(us[k], w, h, accum_index=k + 1) for k in range(n)], tg)
+        assert np.array_equal(bits(buf), bits(ref)), (pipe, sub)
+    # frames of a sequence must agree in geometry
+    with pytest.raises(api.RtError):
+        sc.render_sequence_raw([api.make_frame(us[0], w, h), api.make_frame(us[1], w, h - 16, accum_index=2)], tg)
+    sc.close()
+
+
+def _sphere_field_poses():
+    """Camera poses chosen to stress the culling of the sphere loop: inside / on the faces of the slab that holds the
+    small spheres, axis-parallel and grazing views, eyes on cell boundaries of the sphere grid, eyes near and beyond
+    the distance up to which culling is used, plus seeded random poses."""
+    poses = [
+        ((0.0, 0.2, 0.0), (5.0, 0.2, 0.0)), ((0.0, 0.2, 0.0), (0.0, 0.2, -5.0)), ((1.0, 0.45, 1.0), (8.0, 0.45, 1.0)),
+        ((1.0, -0.05, 1.0), (8.0, 0.3, 2.0)), ((-8.245381, 0.2, -7.0), (9.0, 0.2, -7.0)), ((-6.245381, 0.3, -9.0), (-6.245381, 0.3, 9.0)),
+        ((-12.0, 0.25, -12.0), (12.0, 0.25, 12.0)), ((0.3, 6.0, 0.3), (0.3, 0.0, 0.3001)), ((31.9, 3.0, 0.0), (0.0, 0.0, 0.0)),
+        ((32.1, 3.0, 0.0), (0.0, 0.0, 0.0)), ((200.0, 40.0, 150.0), (0.0, 0.0, 0.0)), ((2.0, 0.1, 2.0), (2.5, 3.0, 2.2)),
+        ((-4.0, 2.0, 3.5), (-4.0, 2.0, 0.0)), ((0.0, 30.0, 0.0), (0.01, 0.0, 0.0)), ((9.5, 0.21, 9.5), (-9.0, 0.19, -9.0)),
+    ]
+    rng = np.random.default_rng(7)
+    for _ in range(12):
+        eye = rng.uniform(-11.0, 11.0, 3); eye[1] = rng.uniform(-0.2, 6.0)
+        at = rng.uniform(-8.0, 8.0, 3); at[1] = rng.uniform(0.0, 2.0)
+        poses.append((tuple(float(x) for x in eye), tuple(float(x) for x in at)))
+    return poses
+
+
+@pytest.mark.parametrize("pipeline", ["wavefront", "megakernel", "persistent"])
+def test_sphere_field_poses_bit_exact(test_sky, pipeline):
+    from oracle import oracle
+    d = dict(vertices=np.zeros((1, 4), np.float32), normals=np.zeros((1, 4), np.float32), tri_refs=np.zeros((1, 4), np.uint32), nodes=np.zeros((0,), np.uint32),
+             bounds_min=np.zeros(3, np.float32), bounds_max=np.zeros(3, np.float32))
+    sc = api.Scene.from_dict(d)
+    sc.set_skybox(test_sky)
+    sc.set_pipeline(pipeline)
+    osc = oracle.OracleScene(d, test_sky)
+    w, h = 192, 128
+    for i, (eye, at) in enumerate(_sphere_field_poses()):
+        u = Uniforms.from_camera(Camera(eye=eye, at=at, aspect=w / h), time=0.25 * i, max_recursion_limit=6, blur_amount=1e-5 if i % 3 else 0.02).pack()
+        compare(osc.render(u, w, h), sc.render(u, w, h), "pose %d %s" % (i, (eye, at)))
     sc.close()

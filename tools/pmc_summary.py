@@ -8,7 +8,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         name = row["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name in sorted(acc):
-    if not any(k in name for k in ("render", "spheres", "traverse", "shade")):
+    if not any(k in name for k in ("render", "spheres", "traverse", "shade", "path")):
         continue
     print(name)
     for c in sorted(acc[name]):

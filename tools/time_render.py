@@ -20,31 +20,36 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--pipelines", default="wavefront,megakernel")
-    ap.add_argument("--subframes", type=int, default=4)
+    ap.add_argument("--subframes", default="4", help="comma list of sub-frame counts")
+    ap.add_argument("--sequence", action="store_true", help="issue the timed frames as one rt_render_sequence call")
     a = ap.parse_args()
     sky = scenes.procedural_skybox(900)
     W, H = a.width, a.height
     color = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     for name in a.scenes.split(","):
         d = empty_scene() if name == "empty" else {"bunny": scenes.default_octree, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "small": scenes.small_test_scene}[name]().as_dict()
-        sc = api.Scene.from_dict(d); sc.set_skybox(sky); sc.set_subframes(a.subframes)
-        for pipe, lim in [(p, int(x)) for p in a.pipelines.split(",") for x in a.limits.split(",")]:
-            sc.set_pipeline(pipe)
+        sc = api.Scene.from_dict(d); sc.set_skybox(sky)
+        for pipe, lim, sub in [(p, int(x), int(k)) for p in a.pipelines.split(",") for x in a.limits.split(",") for k in (a.subframes.split(",") if p != "megakernel" else ["1"])]:
+            sc.set_pipeline(pipe); sc.set_subframes(sub)
             def run(k, sync=False):
                 u = Uniforms.from_camera(Camera(aspect=W / H), time=k / 60.0, max_recursion_limit=lim).pack()
                 fr = api.make_frame(u, W, H, accum_index=k + 1, stream=torch.cuda.current_stream().cuda_stream)
-                tg = api.rt_target(); tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, int(sync), color.data_ptr()
+                tg = api.rt_target(); tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, int(bool(sync)), color.data_ptr()
+                if sync is None: return fr, tg
                 sc.render_raw(fr, tg)
             run(0); run(1); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for k in range(a.reps): run(k)
+            if a.sequence:
+                sc.render_sequence_raw([run(k, None)[0] for k in range(a.reps)], run(0, None)[1])
+            else:
+                for k in range(a.reps): run(k)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / a.reps * 1e3
             extra = ""
             if a.count:
                 sc.set_counting(True); run(0, True); st = sc.stats(); sc.set_counting(False)
                 extra = f" rays={st['rays']} Mrays/s={st['rays'] / ms / 1e3:.0f} pops={st['node_pops']} tri={st['triangle_tests']} box={st['child_box_tests']} enter={st['rays_entering_octree']}"
-            print(f"{name:8s} {pipe:10s} limit={lim} {W}x{H}: {ms:.3f} ms/frame{extra}", flush=True)
+            print(f"{name:8s} {pipe:10s} sub={sub} seq={int(a.sequence)} limit={lim} {W}x{H}: {ms:.3f} ms/frame{extra}", flush=True)
         sc.close()
 
 if __name__ == "__main__":
