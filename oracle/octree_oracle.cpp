@@ -16,7 +16,7 @@
  * for stanford_bunny.obj (529 434 triangle references, 654 908 node words, depth 17) recorded
  * when the reference was surveyed, SHA-256 digests of that survey run's four output arrays
  * (tests/golden/bunny_octree_digest.json), and the independent second implementation in the product
- * (raytracer_amd/csrc/rt_octree_build.cpp) that must agree with this one bit-for-bit.
+ * (raytracer_amd/csrc/rt_host_build.cpp) that must agree with this one bit-for-bit.
  * OBJ text parsing in the reference goes through tinyobjloader 2.0.0-rc10 (not vendored, absent):
  * the decimal->float conversion here is strtod + cast, unpinned; only triangle faces are accepted.
  */

@@ -1,0 +1,58 @@
+// Small C++ caller of rt_host.hpp, used by the tests: builds the octree of a triangle soup read from a file with the
+// reference-named classes and optionally renders frames into device memory like the reference's App would.
+//   host_demo <mesh.bin> <out.bin> [<uniforms.bin> <width> <height> <n_frames>]
+// mesh.bin: u32 n_vert, u32 n_face, f32 pos[n_vert][3], u32 face[n_face][3]
+// out.bin:  u64 n_vert, n_ref, n_words, f32 min[3], max[3], then vertices, normals, tri refs, node words;
+//           with rendering: f32 rgba[height][width][4] and f32 depth[height][width] after n_frames accumulated draws
+// uniforms.bin: n_frames x 70 words (rt_uniforms)
+#include <cstdio>
+#include <cstdlib>
+#include <hip/hip_runtime_api.h>
+#include "rt_host.hpp"
+
+static void put(FILE *f, const void *p, size_t n) { if (n && fwrite(p, 1, n, f) != n) { perror("write"); exit(2); } }
+
+int main(int argc, char **argv) {
+    if (argc != 3 && argc != 7) { fprintf(stderr, "usage: host_demo mesh.bin out.bin [uniforms.bin w h n]\n"); return 2; }
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) { perror(argv[1]); return 2; }
+    uint32_t nv = 0, nf = 0;
+    if (fread(&nv, 4, 1, in) != 1 || fread(&nf, 4, 1, in) != 1) return 2;
+    std::vector<rt::vec3> pos(nv);
+    std::vector<uint32_t> faces(3 * (size_t)nf);
+    if (fread(pos.data(), sizeof(rt::vec3), nv, in) != nv || fread(faces.data(), 12, nf, in) != nf) return 2;
+    fclose(in);
+    try {
+        rt::Mesh mesh(pos, {}, faces, 1, rt::mat4::scale(2.0f));
+        rt::Octree octree(std::vector<rt::Mesh>{mesh}, 18, 10, 6, 6);   // App.cpp:22
+        FILE *out = fopen(argv[2], "wb");
+        if (!out) { perror(argv[2]); return 2; }
+        const uint64_t sizes[3] = {octree.m_vertecies.size(), octree.m_compressed_triangles.size(), octree.m_compressed_node_buffer.size()};
+        const rt::vec3 lo = octree.GetMinBounds(), hi = octree.GetMaxBounds();
+        put(out, sizes, sizeof sizes); put(out, &lo, 12); put(out, &hi, 12);
+        put(out, octree.m_vertecies.data(), sizes[0] * 16); put(out, octree.m_normals.data(), sizes[0] * 16);
+        put(out, octree.m_compressed_triangles.data(), sizes[1] * 16); put(out, octree.m_compressed_node_buffer.data(), sizes[2] * 4);
+        if (argc == 7) {
+            const uint32_t w = (uint32_t)atoi(argv[4]), h = (uint32_t)atoi(argv[5]), n = (uint32_t)atoi(argv[6]);
+            std::vector<rt_uniforms> u(n);
+            FILE *uf = fopen(argv[3], "rb");
+            if (!uf || fread(u.data(), sizeof(rt_uniforms), n, uf) != n) { fprintf(stderr, "cannot read uniforms\n"); return 2; }
+            fclose(uf);
+            float *color = nullptr, *depth = nullptr;
+            if (hipMalloc((void **)&color, (size_t)w * h * 16) != hipSuccess || hipMalloc((void **)&depth, (size_t)w * h * 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 3; }
+            (void)hipMemset(color, 0, (size_t)w * h * 16);
+            rt::RayTracePass pass(octree);
+            pass.Render(u[0], w, h, color, depth, nullptr, true);                       // one draw ...
+            if (n > 1) pass.RenderFrames(std::vector<rt_uniforms>(u.begin() + 1, u.end()), w, h, color, depth, nullptr, true);   // ... then the rest as a sequence
+            std::vector<float> hc((size_t)w * h * 4), hd((size_t)w * h);
+            if (hipMemcpy(hc.data(), color, hc.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hd.data(), depth, hd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+            put(out, hc.data(), hc.size() * 4); put(out, hd.data(), hd.size() * 4);
+            (void)hipFree(color); (void)hipFree(depth);
+        }
+        fclose(out);
+    } catch (const rt::Error &e) {
+        fprintf(stderr, "rt error %d: %s\n", e.code(), e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,157 @@
+// C++ host side of the MI355X ray-tracing pass: the scene classes and the render pass of the reference application
+// with their member and method names, implemented on the C ABI of include/rt_hotpath.h (header-only, no GL, no glm).
+//
+//   Mesh        mirrors Mesh        (app/core/include/Mesh.hpp:9-20,   app/core/src/Mesh.cpp:11-101)
+//   Octree      mirrors Octree      (app/core/include/Octree.hpp:25-36, app/core/src/Octree.cpp:203-256)
+//   RayTracePass replaces what App keeps for the ray-tracing draw: the four storage buffers (App.cpp:23-26), the
+//               skybox texture (Skybox.cpp:46-57), the accumulation counter (App.cpp:29,90-92,104-105,209) and the
+//               draw itself (App.cpp:107-140)
+//
+// Errors are reported as rt::Error exceptions carrying the ABI's status code and message; the reference logs and
+// exits (Mesh.cpp:20-26) or logs and continues (GL).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hotpath.h"
+
+namespace rt {
+
+struct vec3 { float x, y, z; };
+struct vec4 { float x, y, z, w; };
+struct uvec4 { uint32_t x, y, z, w; };
+struct mat4 {   // column-major, as glm::value_ptr yields it
+    float m[16];
+    static mat4 identity() { mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+    static mat4 scale(float s) { mat4 r = identity(); r.m[0] = r.m[5] = r.m[10] = s; return r; }
+};
+
+class Error : public std::runtime_error {
+public:
+    Error(int code, const char *msg) : std::runtime_error(msg ? msg : "rt error"), m_code(code) {}
+    int code() const { return m_code; }
+private:
+    int m_code;
+};
+inline void check(int rc) { if (rc != RT_OK) throw Error(rc, rt_last_error()); }
+
+class Mesh {
+public:
+    Mesh(const std::string &filename, size_t material_id, mat4 transform = mat4::identity()) {
+        rt_mesh m{};
+        check(rt_mesh_load_obj(filename.c_str(), (uint32_t)material_id, transform.m, &m));
+        adopt(m);
+    }
+    // From arrays already in memory: positions [n], optional normals [n] (empty: accumulated face normals), faces.
+    Mesh(const std::vector<vec3> &positions, const std::vector<vec3> &file_normals, const std::vector<uint32_t> &faces, size_t material_id, mat4 transform = mat4::identity()) {
+        rt_mesh m{};
+        check(rt_mesh_from_arrays(&positions[0].x, file_normals.empty() ? nullptr : &file_normals[0].x, positions.size(), faces.data(), faces.size() / 3,
+                                  (uint32_t)material_id, transform.m, &m));
+        adopt(m);
+    }
+    std::vector<vec4> m_vertecies;
+    std::vector<vec4> m_normals;
+    std::vector<uvec4> m_triangles;
+private:
+    void adopt(rt_mesh &m) {
+        m_vertecies.resize(m.n_vert); m_normals.resize(m.n_vert); m_triangles.resize(m.n_tri);
+        if (m.n_vert) { std::memcpy(m_vertecies.data(), m.vertices, m.n_vert * sizeof(vec4)); std::memcpy(m_normals.data(), m.normals, m.n_vert * sizeof(vec4)); }
+        if (m.n_tri) std::memcpy(m_triangles.data(), m.triangles, m.n_tri * sizeof(uvec4));
+        rt_mesh_free(&m);
+    }
+};
+
+class Octree {
+public:
+    Octree(const std::vector<Mesh> &meshes, size_t depth_limit, size_t max_triangles_per_node, size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps) {
+        std::vector<rt_mesh> in(meshes.size());
+        for (size_t i = 0; i < meshes.size(); i++) {
+            const Mesh &m = meshes[i];
+            in[i].vertices = const_cast<float *>(m.m_vertecies.empty() ? nullptr : &m.m_vertecies[0].x);
+            in[i].normals = const_cast<float *>(m.m_normals.empty() ? nullptr : &m.m_normals[0].x);
+            in[i].triangles = const_cast<uint32_t *>(m.m_triangles.empty() ? nullptr : &m.m_triangles[0].x);
+            in[i].n_vert = m.m_vertecies.size(); in[i].n_tri = m.m_triangles.size();
+        }
+        rt_octree o{};
+        check(rt_octree_build(in.data(), in.size(), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, &o));
+        m_vertecies.resize(o.n_vert); m_normals.resize(o.n_vert); m_compressed_triangles.resize(o.n_ref); m_compressed_node_buffer.resize(o.n_words);
+        if (o.n_vert) { std::memcpy(m_vertecies.data(), o.vertices, o.n_vert * sizeof(vec4)); std::memcpy(m_normals.data(), o.normals, o.n_vert * sizeof(vec4)); }
+        if (o.n_ref) std::memcpy(m_compressed_triangles.data(), o.tri_refs, o.n_ref * sizeof(uvec4));
+        if (o.n_words) std::memcpy(m_compressed_node_buffer.data(), o.nodes, o.n_words * sizeof(uint32_t));
+        m_min = {o.bounds_min[0], o.bounds_min[1], o.bounds_min[2]}; m_max = {o.bounds_max[0], o.bounds_max[1], o.bounds_max[2]};
+        m_max_depth = o.max_depth;
+        rt_octree_free(&o);
+    }
+    vec3 GetMinBounds() const { return m_min; }
+    vec3 GetMaxBounds() const { return m_max; }
+    size_t GetMaxDepth() const { return m_max_depth; }
+
+    std::vector<vec4> m_vertecies;
+    std::vector<vec4> m_normals;
+    std::vector<uint32_t> m_compressed_node_buffer;
+    std::vector<uvec4> m_compressed_triangles;
+private:
+    vec3 m_min{}, m_max{};
+    size_t m_max_depth = 0;
+};
+
+// The ray-tracing draw with its state.  The colour target is a caller-owned linear RGBA32F image in device memory
+// ([height][width][4] floats, row 0 at the bottom) that persists across frames, like the reference's framebuffer
+// attachment (Framebuffer.cpp:6); depth is optional.
+class RayTracePass {
+public:
+    explicit RayTracePass(const Octree &octree) {
+        const vec3 lo = octree.GetMinBounds(), hi = octree.GetMaxBounds();
+        const float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
+        check(rt_scene_create(octree.m_vertecies.empty() ? nullptr : &octree.m_vertecies[0].x, octree.m_normals.empty() ? nullptr : &octree.m_normals[0].x, octree.m_vertecies.size(),
+                              octree.m_compressed_triangles.empty() ? nullptr : &octree.m_compressed_triangles[0].x, octree.m_compressed_triangles.size(),
+                              octree.m_compressed_node_buffer.data(), octree.m_compressed_node_buffer.size(), bmin, bmax, &m_scene));
+    }
+    ~RayTracePass() { (void)rt_scene_destroy(m_scene); }
+    RayTracePass(const RayTracePass &) = delete;
+    RayTracePass &operator=(const RayTracePass &) = delete;
+
+    // Six RGBA8 faces in the order +x,-x,+y,-y,+z,-z (Skybox.cpp:46-57).
+    void SetSkybox(const uint8_t *const faces[6], int w, int h) { check(rt_skybox_set(m_scene, faces, w, h)); }
+    // App.cpp:90-92,209: any camera change or resize restarts the accumulation.
+    void ResetAccumulation() { m_still_frame_counter = 1; }
+    uint32_t StillFrameCounter() const { return m_still_frame_counter; }
+
+    // App::Render's ray-tracing draw (App.cpp:97-140) into device memory; sync = false returns after the enqueue.
+    void Render(const rt_uniforms &u, uint32_t width, uint32_t height, float *color_dev, float *depth_dev = nullptr, void *stream = nullptr, bool sync = false) {
+        const rt_frame f = Frame(u, width, height, stream);
+        const rt_target t = Target(color_dev, depth_dev, sync);
+        check(rt_render(m_scene, &f, &t));
+    }
+    // n consecutive draws with an unchanged camera (uniforms differ in `time` only), issued as one sequence.
+    void RenderFrames(const std::vector<rt_uniforms> &u, uint32_t width, uint32_t height, float *color_dev, float *depth_dev = nullptr, void *stream = nullptr, bool sync = false) {
+        std::vector<rt_frame> f;
+        f.reserve(u.size());
+        for (const rt_uniforms &ui : u) f.push_back(Frame(ui, width, height, stream));
+        const rt_target t = Target(color_dev, depth_dev, sync);
+        check(rt_render_sequence(m_scene, f.data(), f.size(), &t));
+    }
+    rt_scene *Handle() { return m_scene; }
+private:
+    rt_frame Frame(const rt_uniforms &u, uint32_t width, uint32_t height, void *stream) {
+        rt_frame f{};
+        f.u = u; f.width = width; f.height = height;
+        f.accum_index = m_still_frame_counter++;   // App.cpp:104-105
+        f.blend = 1;                               // App.cpp:102
+        f.band_rows = 16; f.band_parts = 1; f.band_part = 0;
+        f.stream = stream;
+        return f;
+    }
+    static rt_target Target(float *color_dev, float *depth_dev, bool sync) {
+        rt_target t{};
+        t.memory = RT_MEM_DEVICE; t.sync = sync ? 1 : 0; t.color = color_dev; t.depth = depth_dev;
+        return t;
+    }
+    rt_scene *m_scene = nullptr;
+    uint32_t m_still_frame_counter = 1;            // App.cpp:29
+};
+
+}  // namespace rt

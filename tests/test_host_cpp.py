@@ -1,0 +1,81 @@
+"""The C++ host mirror (raytracer_amd/host/rt_host.hpp) driven by its demo program: the reference-named Mesh / Octree
+classes give the arrays the Python mirror gives (same C ABI underneath), and RayTracePass accumulates frames in device
+memory to the same bits as Scene.render."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api
+from raytracer_amd.camera import Camera
+from raytracer_amd.params import Uniforms
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "raytracer_amd", "host", "host_demo")
+
+
+def _soup(seed=5, n_tri=400):
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-0.6, 0.6, (n_tri, 1, 3)) + np.array([0.0, 0.75, 0.0])
+    pos = (centres + rng.uniform(-0.08, 0.08, (n_tri, 3, 3))).reshape(-1, 3).astype(np.float32)
+    faces = np.arange(3 * n_tri, dtype=np.uint32).reshape(-1, 3)
+    return pos, faces
+
+
+def _run_demo(tmp_path, pos, faces, render=None):
+    mesh_bin, out_bin = tmp_path / "mesh.bin", tmp_path / "out.bin"
+    with open(mesh_bin, "wb") as f:
+        f.write(np.array([len(pos), len(faces)], np.uint32).tobytes()); f.write(pos.tobytes()); f.write(faces.tobytes())
+    cmd = [DEMO, str(mesh_bin), str(out_bin)]
+    if render:
+        us, w, h = render
+        (tmp_path / "u.bin").write_bytes(np.concatenate(us).astype(np.float32).tobytes())
+        cmd += [str(tmp_path / "u.bin"), str(w), str(h), str(len(us))]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = out_bin.read_bytes()
+    nv, nr, nw = np.frombuffer(raw, np.uint64, 3)
+    off = 24
+    def take(dtype, count):
+        nonlocal off
+        a = np.frombuffer(raw, dtype, int(count), off); off += a.nbytes
+        return a
+    d = dict(bounds_min=take(np.float32, 3), bounds_max=take(np.float32, 3), vertices=take(np.float32, nv * 4).reshape(-1, 4), normals=take(np.float32, nv * 4).reshape(-1, 4),
+             tri_refs=take(np.uint32, nr * 4).reshape(-1, 4), nodes=take(np.uint32, nw))
+    if render:
+        us, w, h = render
+        d["rgba"] = take(np.float32, w * h * 4).reshape(h, w, 4); d["depth"] = take(np.float32, w * h).reshape(h, w)
+    assert off == len(raw)
+    return d
+
+
+def _python_octree(pos, faces):
+    mesh = api.Mesh(positions=pos, faces=faces, material_id=1, transform=api.scale_matrix(2.0))
+    return api.Octree([mesh], 18, 10, 6, 6)
+
+
+def test_cpp_octree_equals_python_mirror(tmp_path):
+    pos, faces = _soup()
+    d = _run_demo(tmp_path, pos, faces)
+    o = _python_octree(pos, faces).as_dict()
+    for k in ("vertices", "normals", "bounds_min", "bounds_max"):
+        assert np.array_equal(d[k].view(np.uint32), np.ascontiguousarray(o[k], np.float32).view(np.uint32).reshape(d[k].shape)), k
+    assert np.array_equal(d["tri_refs"], o["tri_refs"].reshape(-1, 4)) and np.array_equal(d["nodes"], o["nodes"])
+    assert len(d["nodes"]) > 100
+
+
+@pytest.mark.gpu
+def test_cpp_render_pass_accumulates_like_scene_render(tmp_path):
+    pos, faces = _soup()
+    w, h, n = 160, 96, 3
+    us = [Uniforms.from_camera(Camera(aspect=w / h), time=k / 60.0).pack() for k in range(n)]
+    d = _run_demo(tmp_path, pos, faces, render=(us, w, h))
+    sc = api.Scene.from_octree(_python_octree(pos, faces))   # no skybox in either: texture() returns 0
+    acc, depth = None, None
+    for k in range(n):
+        r = sc.render(us[k], w, h, accum_index=k + 1, color=acc, planes=False)
+        acc, depth = r["rgba"], r["depth"]
+    sc.close()
+    assert np.array_equal(d["rgba"].view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(d["depth"].view(np.uint32), depth.view(np.uint32))
