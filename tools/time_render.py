@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--pipelines", default="wavefront,megakernel")
     ap.add_argument("--subframes", default="4", help="comma list of sub-frame counts")
+    ap.add_argument("--host", action="store_true", help="host-memory target: every frame is staged over PCIe")
     ap.add_argument("--sequence", action="store_true", help="issue the timed frames as one rt_render_sequence call")
     a = ap.parse_args()
     sky = scenes.procedural_skybox(900)
@@ -31,7 +32,12 @@ def main():
         sc = api.Scene.from_dict(d); sc.set_skybox(sky)
         for pipe, lim, sub in [(p, int(x), int(k)) for p in a.pipelines.split(",") for x in a.limits.split(",") for k in (a.subframes.split(",") if p != "megakernel" else ["1"])]:
             sc.set_pipeline(pipe); sc.set_subframes(sub)
+            host_color = np.zeros((H, W, 4), np.float32)
             def run(k, sync=False):
+                if a.host:
+                    u = Uniforms.from_camera(Camera(aspect=W / H), time=k / 60.0, max_recursion_limit=lim).pack()
+                    sc.render(u, W, H, accum_index=k + 1, color=host_color, planes=False)
+                    return
                 u = Uniforms.from_camera(Camera(aspect=W / H), time=k / 60.0, max_recursion_limit=lim).pack()
                 fr = api.make_frame(u, W, H, accum_index=k + 1, stream=torch.cuda.current_stream().cuda_stream)
                 tg = api.rt_target(); tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, int(bool(sync)), color.data_ptr()
