@@ -148,14 +148,20 @@ int rt_scene_set_counting(rt_scene *scene, int enabled);
 int rt_scene_set_kernel_timing(rt_scene *scene, int enabled);
 int rt_scene_kernel_time(rt_scene *scene, double *total_ms, uint32_t *launches);
 /* Selects how a frame is executed (results are bit-identical):
- *   RT_PIPELINE_PERSISTENT (default)  one kernel of resident waves; every lane carries one path at a time, lanes
+ *   RT_PIPELINE_AUTO (default)  the scene times the three pipelines below on its own frames (a few frames after a change
+ *       of frame size, recursion limit or band split, and again now and then) and uses the fastest: which one that is
+ *       depends on how much of the work is octree traversal;
+ *   RT_PIPELINE_PERSISTENT  one kernel of resident waves; every lane carries one path at a time, lanes
  *       alternate between octree traversal and a batched "segment block" (hit assembly, scattering, next pixel,
  *       sphere tests), and free lanes take new pixels from global tile counters;
  *   RT_PIPELINE_WAVEFRONT  one pass per path depth: sphere tests, a persistent octree-traversal kernel fed from a
  *       queue, shading with compaction of the surviving paths into the next depth's queue;
- *   RT_PIPELINE_MEGAKERNEL  a pixel's whole path in one lane of one kernel (the simple cross-check). */
-enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1, RT_PIPELINE_PERSISTENT = 2 };
+ *   RT_PIPELINE_MEGAKERNEL  a pixel's whole path in one lane of one kernel: fastest when most rays miss the octree. */
+enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1, RT_PIPELINE_PERSISTENT = 2, RT_PIPELINE_AUTO = 3 };
 int rt_scene_set_pipeline(rt_scene *scene, int pipeline);
+/* The pipeline the next frame would run with and, under RT_PIPELINE_AUTO, the per-frame milliseconds measured so far
+ * for RT_PIPELINE_MEGAKERNEL / WAVEFRONT / PERSISTENT (index = enum value; negative: not measured yet). */
+int rt_scene_pipeline_state(rt_scene *scene, int *selected, double ms_per_frame[3]);
 /* Persistent and wavefront pipelines: a frame is rendered as up to n (1..8, default 2) interleaved sub-frames whose
  * kernels run on separate internal streams, forked from and joined to rt_frame.stream, so that the sparse end of one
  * sub-frame overlaps dense work of another (most effective inside rt_render_sequence).  Results do not depend on n. */

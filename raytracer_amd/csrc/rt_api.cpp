@@ -56,7 +56,7 @@ struct rt_scene {
     size_t s_pixels = 0;
     // wavefront pipeline: a frame is cut into up to RT_MAX_SUBFRAMES interleaved sub-frames that run as independent
     // kernel chains on their own streams, so that the sparse tail of one chain overlaps the dense kernels of another
-    int pipeline = RT_PIPELINE_PERSISTENT;
+    int pipeline = RT_PIPELINE_AUTO;
     int subframes = 2;
     struct Sub {
         RtWorkspace ws{};
@@ -69,6 +69,18 @@ struct rt_scene {
     } sub[RT_MAX_SUBFRAMES];
     bool timing = false;
     hipEvent_t fork_ev = nullptr;
+    // RT_PIPELINE_AUTO: the three pipelines give identical pixels, so the scene measures them on its own frames (event
+    // pairs around a call's launches, read back without blocking at a later call) and uses the fastest for the workload
+    // at hand; the others are measured again now and then.
+    struct Tuner {
+        uint64_t key = 0;                  // frame size / recursion limit / band split the measurements belong to
+        double ms[3] = {-1.0, -1.0, -1.0};  // per-frame time of each pipeline (< 0: not measured yet)
+        uint32_t seen[3] = {0, 0, 0};       // measurements taken (the first one of a pipeline is a warm-up and is dropped)
+        uint32_t calls = 0;
+        int pending = -1;                  // pipeline of the measurement in flight
+        uint32_t pending_frames = 0;
+        hipEvent_t a = nullptr, b = nullptr;
+    } tuner;
 };
 
 namespace {
@@ -331,8 +343,16 @@ int rt_skybox_set(rt_scene *s, const uint8_t *const faces[6], int w, int h) {
 
 int rt_scene_set_pipeline(rt_scene *s, int pipeline) {
     if (!s) return fail(RT_EINVAL, "scene is null");
-    if (pipeline != RT_PIPELINE_MEGAKERNEL && pipeline != RT_PIPELINE_WAVEFRONT && pipeline != RT_PIPELINE_PERSISTENT) return fail(RT_EINVAL, "unknown pipeline %d", pipeline);
+    if (pipeline < RT_PIPELINE_MEGAKERNEL || pipeline > RT_PIPELINE_AUTO) return fail(RT_EINVAL, "unknown pipeline %d", pipeline);
     s->pipeline = pipeline;
+    return RT_OK;
+}
+
+int rt_scene_pipeline_state(rt_scene *s, int *selected, double ms_per_frame[3]) {
+    if (!s || !selected || !ms_per_frame) return fail(RT_EINVAL, "null argument");
+    int best = -1;
+    for (int p = 0; p < 3; p++) { ms_per_frame[p] = s->tuner.ms[p]; if (s->tuner.ms[p] >= 0.0 && (best < 0 || s->tuner.ms[p] < s->tuner.ms[best])) best = p; }
+    *selected = s->pipeline != RT_PIPELINE_AUTO ? s->pipeline : (best >= 0 ? best : RT_PIPELINE_MEGAKERNEL);
     return RT_OK;
 }
 
@@ -358,6 +378,7 @@ int rt_scene_set_kernel_timing(rt_scene *s, int enabled) {
         for (rt_scene::Sub &sb : s->sub) {
             if (!sb.probe.events) {
                 sb.probe.events = new hipEvent_t[2 * RT_PROBE_PAIRS]();
+                sb.probe.launches = new uint32_t[RT_PROBE_PAIRS]();
                 sb.probe.capacity = RT_PROBE_PAIRS;
                 for (uint32_t i = 0; i < 2 * RT_PROBE_PAIRS; i++) HIP_TRY(hipEventCreate(&sb.probe.events[i]));
             }
@@ -378,7 +399,7 @@ int rt_scene_kernel_time(rt_scene *s, double *total_ms, uint32_t *launches) {
         for (uint32_t i = 0; i < sb.probe.used; i++) {
             float t = 0.0f;
             HIP_TRY(hipEventElapsedTime(&t, sb.probe.events[2 * i], sb.probe.events[2 * i + 1]));
-            ms += t; n++;
+            ms += t; n += sb.probe.launches[i];
         }
         sb.probe.used = 0;
     }
@@ -404,6 +425,34 @@ static uint32_t band_rows_of(const rt_frame *f) {
     return mine * f->band_rows;
 }
 uint32_t rt_band_row_count(const rt_frame *f) { return band_rows_of(f); }
+
+// RT_PIPELINE_AUTO: collects a finished measurement, then picks the pipeline of this call and says whether to time it.
+static int tuner_choose(rt_scene *s, uint64_t key, bool *measure) {
+    rt_scene::Tuner &t = s->tuner;
+    *measure = false;
+    if (!t.a && (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess)) { t.a = t.b = nullptr; return RT_PIPELINE_MEGAKERNEL; }
+    if (t.pending >= 0 && hipEventQuery(t.b) == hipSuccess) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && t.pending_frames > 0) {
+            const double per_frame = (double)ms / t.pending_frames;
+            const int p = t.pending;
+            if (t.seen[p]++ > 0) t.ms[p] = t.ms[p] < 0.0 ? per_frame : 0.5 * (t.ms[p] + per_frame);
+        }
+        t.pending = -1;
+    }
+    if (key != t.key) { t.key = key; for (int p = 0; p < 3; p++) { t.ms[p] = -1.0; t.seen[p] = 0; } t.calls = 0; }
+    t.calls++;
+    int best = -1;
+    for (int p = 0; p < 3; p++) if (t.ms[p] >= 0.0 && (best < 0 || t.ms[p] < t.ms[best])) best = p;
+    int choice = best >= 0 ? best : RT_PIPELINE_MEGAKERNEL;
+    if (t.pending < 0) {
+        *measure = true;
+        for (int p = 0; p < 3; p++) if (t.ms[p] < 0.0) { choice = p; break; }                 // something still unknown: try it
+        if (best >= 0 && t.ms[0] >= 0.0 && t.ms[1] >= 0.0 && t.ms[2] >= 0.0 && t.calls % 64u == 0u)
+            choice = (best + 1 + (int)((t.calls / 64u) % 2u)) % 3;                            // look at the others again now and then
+    }
+    return choice;
+}
 
 // Frames of one sequence share everything that decides which pixels a launch owns and where they live.
 static bool same_geometry(const rt_frame &a, const rt_frame &b) {
@@ -443,8 +492,14 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
 
     L.sub_parts = 1; L.sub_part = 0;
-    const bool wavefront = s->pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
-    const bool persistent = s->pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
+    int pipeline = s->pipeline;
+    bool measure = false;
+    if (pipeline == RT_PIPELINE_AUTO) {
+        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0);
+        pipeline = tuner_choose(s, key + 1, &measure);
+    }
+    const bool wavefront = pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
+    const bool persistent = pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
     // number of sub-frames: every one should still fill the machine (>= 64 strips of 16 rows x width)
     uint32_t K = 1;
     if (wavefront || persistent) {
@@ -472,7 +527,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     // Otherwise K sub-frame chains are forked from the caller's stream once, each runs its share of every frame
     // in order on its own stream (a pixel belongs to one sub-frame, so its accumulation order is kept), and all
     // are joined back once: the chains drift apart and the sparse end of one kernel overlaps dense work of others.
-    auto launch_all = [&](const RtLaunch &L0, const char **kerr) -> int {
+    auto launch_frames = [&](const RtLaunch &L0, const char **kerr) -> int {
         auto frame_launch = [&](size_t i, uint32_t parts, uint32_t part) {
             RtLaunch Li = L0;
             Li.u = frames[i].u; Li.accum_index = frames[i].accum_index; Li.blend = frames[i].blend ? 1u : 0u;
@@ -487,7 +542,22 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             }
             return Li;
         };
-        if ((!wavefront && !persistent) || K == 1) {
+        if (!wavefront && !persistent) {
+            // one kernel per frame, back to back on one stream: a single event pair around the whole sequence gives the
+            // average launch duration without putting a timing event between every two launches
+            RtProbe *pr = s->timing && s->sub[0].probe.used < s->sub[0].probe.capacity ? &s->sub[0].probe : nullptr;
+            if (pr && hipEventRecord(pr->events[2 * pr->used], st) != hipSuccess) return 1;
+            for (size_t i = 0; i < n_frames; i++) {
+                int rc = rt_launch_render(s->d, frame_launch(i, 1, 0), nullptr, nullptr, st, kerr, nullptr);
+                if (rc != 0) return rc;
+            }
+            if (pr) {
+                if (hipEventRecord(pr->events[2 * pr->used + 1], st) != hipSuccess) return 1;
+                pr->launches[pr->used++] = (uint32_t)n_frames;
+            }
+            return 0;
+        }
+        if (K == 1) {
             for (size_t i = 0; i < n_frames; i++) {
                 const bool wf = wavefront && frames[i].u.max_recursion_limit >= 1;
                 int rc = rt_launch_render(s->d, frame_launch(i, 1, 0), wf ? &s->sub[0].ws : nullptr, (persistent && frames[i].u.max_recursion_limit >= 1) ? s->sub[0].pool : nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr);
@@ -506,6 +576,14 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             if (hipEventRecord(s->sub[j].done, s->sub[j].stream) != hipSuccess) return 1;
             if (hipStreamWaitEvent(st, s->sub[j].done, 0) != hipSuccess) return 1;
         }
+        return 0;
+    };
+    auto launch_all = [&](const RtLaunch &L0, const char **kerr) -> int {
+        if (!measure) return launch_frames(L0, kerr);
+        if (hipEventRecord(s->tuner.a, st) != hipSuccess) return 1;
+        const int rc = launch_frames(L0, kerr);
+        if (rc != 0 || hipEventRecord(s->tuner.b, st) != hipSuccess) return rc != 0 ? rc : 1;
+        s->tuner.pending = pipeline; s->tuner.pending_frames = (uint32_t)n_frames;
         return 0;
     };
     const size_t px = (size_t)f->width * f->height;                                            // ndc planes
@@ -560,9 +638,11 @@ int rt_scene_destroy(rt_scene *s) {
         if (sb.done) (void)hipEventDestroy(sb.done);
         if (sb.block) (void)hipFree(sb.block);
         if (sb.pool) (void)hipFree(sb.pool);
-        if (sb.probe.events) { for (uint32_t i = 0; i < 2 * sb.probe.capacity; i++) if (sb.probe.events[i]) (void)hipEventDestroy(sb.probe.events[i]); delete[] sb.probe.events; }
+        if (sb.probe.events) { for (uint32_t i = 0; i < 2 * sb.probe.capacity; i++) if (sb.probe.events[i]) (void)hipEventDestroy(sb.probe.events[i]); delete[] sb.probe.events; delete[] sb.probe.launches; }
     }
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+    if (s->tuner.a) (void)hipEventDestroy(s->tuner.a);
+    if (s->tuner.b) (void)hipEventDestroy(s->tuner.b);
     delete s;
     return RT_OK;
 }

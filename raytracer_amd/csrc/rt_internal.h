@@ -81,6 +81,7 @@ struct RtWorkspace {
 // other): pairs of HIP events recorded on the launch stream directly before and after each such launch.
 struct RtProbe {
     hipEvent_t *events;   // [2 * capacity]
+    uint32_t *launches;   // [capacity]: kernel launches bracketed by each pair
     uint32_t capacity;    // pairs
     uint32_t used;        // pairs recorded so far
 };

@@ -454,18 +454,21 @@ DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
     return n;
 }
 
+#ifndef TRI_BATCH
+#define TRI_BATCH 2u   // more in flight costs registers, and with them resident waves
+#endif
 // One visit (frag:456-513) by a single lane: test the node's triangles in order, then the boxes of its children.
 template <bool COUNT>
 DEVI void visit_node(const RtDeviceScene &S, const Ray &r, LevelStack &st, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
     const NodeData n = load_node(S, st.pop_node());
     if (COUNT) { cn.pops++; cn.tri_tests += n.tri_count; cn.box_tests += __popc(n.child_mask); }
-    // triangle records are fetched four at a time so that their memory latencies overlap; they are tested in order
-    for (uint32_t i0 = 0; i0 < n.tri_count; i0 += 4) {
-        TriData td[4];
+    // triangle records are fetched TRI_BATCH at a time so that their memory latencies overlap; they are tested in order
+    for (uint32_t i0 = 0; i0 < n.tri_count; i0 += TRI_BATCH) {
+        TriData td[TRI_BATCH];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) td[k] = load_triangle(S.tris + (n.tri_start + min(i0 + k, n.tri_count - 1u)));
+        for (uint32_t k = 0; k < TRI_BATCH; k++) td[k] = load_triangle(S.tris + (n.tri_start + min(i0 + k, n.tri_count - 1u)));
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
+        for (uint32_t k = 0; k < TRI_BATCH; k++) {
             if (i0 + k < n.tri_count) {
                 const float t = ray_triangle(r, td[k]);
                 if (t >= 0.0f && t < closest) { closest = t; closest_tri = n.tri_start + i0 + k; tri_hit = true; }
@@ -835,8 +838,16 @@ DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
 // ================================================================================================
 // Pipeline 1: one kernel, one lane per pixel for the whole path (kept as the simple cross-check).
 // ================================================================================================
+// Resident waves per SIMD the register allocator must make room for.  The kernel hides the latency of its dependent
+// node and triangle loads only through other waves, so six waves with a few spilled registers beat four without
+// (measured: 1.10 vs 1.24 ms per 4K frame); six is also what the LDS stack allows (6 workgroups x 23 KB per CU).
+#ifndef RENDER_WAVES_PER_SIMD
+#define RENDER_WAVES_PER_SIMD 6
+#endif
+// (the variant for very deep trees needs 46 KB of LDS per workgroup: three fit, so it keeps its registers)
+#define RENDER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3, LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3)))
 template <int LEVELS, bool COUNT>
-__global__ __launch_bounds__(256) void render_kernel(RtDeviceScene S, RtLaunch L) {
+__global__ __launch_bounds__(256) RENDER_OCCUPANCY void render_kernel(RtDeviceScene S, RtLaunch L) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
     __shared__ SphereLds lds_sph;
     stage_spheres(&lds_sph, c_spheres);
@@ -1162,14 +1173,14 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
 #define PATH_TAIL_VISITS 16    // the same once the wave's pixel supply is dry (any waiting lane then triggers a block)
 #endif
 #ifndef PATH_WG_PER_CU
-#define PATH_WG_PER_CU 3       // resident workgroups per CU (register-limited)
+#define PATH_WG_PER_CU 5       // resident workgroups per CU (= PATH_WAVES_PER_SIMD: 4 waves per workgroup, 4 SIMDs per CU)
 #endif
 
 #ifndef PATH_WAVES_PER_SIMD
-#define PATH_WAVES_PER_SIMD 3
+#define PATH_WAVES_PER_SIMD 5
 #endif
 template <int LEVELS, bool COUNT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATH_WAVES_PER_SIMD, PATH_WAVES_PER_SIMD))) void path_kernel(RtDeviceScene S, RtLaunch L, uint32_t *pool, uint32_t n_tiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 20 ? PATH_WAVES_PER_SIMD : 3, LEVELS <= 20 ? PATH_WAVES_PER_SIMD : 3))) void path_kernel(RtDeviceScene S, RtLaunch L, uint32_t *pool, uint32_t n_tiles) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
     __shared__ SphereLds lds_sph;
     stage_spheres(&lds_sph, c_spheres);
@@ -1361,7 +1372,7 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         else if (need <= 20) launch_path<20>(S, L, pool, n_tiles, st, dim3(wgs));
         else launch_path<RT_MAX_TREE_DEPTH + 2>(S, L, pool, n_tiles, st, dim3(wgs));
         mark(1);
-        if (timed) probe->used++;
+        if (timed) probe->launches[probe->used++] = 1;
         rc = (int)hipGetLastError();
     } else if (!WS) {
         const dim3 grid(n_tiles);
@@ -1370,7 +1381,7 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         else if (need <= 20) rc = launch_megakernel<20>(S, L, st, grid);
         else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid);
         mark(1);
-        if (timed) probe->used++;
+        if (timed) probe->launches[probe->used++] = 1;
     } else {
         const bool count = L.counters != nullptr;
         const dim3 grid((uint32_t)rt_workspace_ranges(L.width, L.n_local_rows));   // one workgroup per slot range
@@ -1390,7 +1401,7 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
                 if (need <= 12) launch_traverse<12>(S, L, *WS, d, st, tgrid);
                 else if (need <= 20) launch_traverse<20>(S, L, *WS, d, st, tgrid);
                 else launch_traverse<RT_MAX_TREE_DEPTH + 2>(S, L, *WS, d, st, tgrid);
-                if (t) { mark(1); probe->used++; }
+                if (t) { mark(1); probe->launches[probe->used++] = 1; }
             }
             const uint32_t track = ask ? 1u : 0u;
             if (d == 0) {

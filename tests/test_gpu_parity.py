@@ -230,3 +230,25 @@ def test_sphere_field_poses_bit_exact(test_sky, pipeline):
         u = Uniforms.from_camera(Camera(eye=eye, at=at, aspect=w / h), time=0.25 * i, max_recursion_limit=6, blur_amount=1e-5 if i % 3 else 0.02).pack()
         compare(osc.render(u, w, h), sc.render(u, w, h), "pose %d %s" % (i, (eye, at)))
     sc.close()
+
+
+def test_auto_pipeline_selection_is_invisible(bunny_octree, test_sky):
+    """Under the default automatic selection the library tries every pipeline on its first frames and keeps re-measuring;
+    whichever runs, the frame is the same, and afterwards every pipeline has a measurement."""
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(test_sky)
+    w, h = 512, 384
+    u = Uniforms.from_camera(Camera(aspect=w / h), max_recursion_limit=3).pack()
+    sc.set_pipeline("megakernel")
+    ref = sc.render(u, w, h)
+    sc.set_pipeline("auto")
+    for _ in range(10):
+        g = sc.render(u, w, h)
+        for k in ("rgba", "depth", "t"):
+            assert np.array_equal(bits(g[k]), bits(ref[k])), k
+        for k in ("kind", "slot", "nrays"):
+            assert np.array_equal(g[k], ref[k]), k
+    selected, ms = sc.pipeline_state()
+    assert all(v is not None and v > 0 for v in ms.values()), ms
+    assert selected == min(ms, key=ms.get)
+    sc.close()

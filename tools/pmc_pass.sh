@@ -1,6 +1,6 @@
 #!/bin/bash
-# One rocprofv3 counter pass per argument (comma-free list "A B C") over a short timing run; development aid.
-# usage: tools/pmc_pass.sh <pipeline> <limit> "<counters pass 1>" "<counters pass 2>" ...
+# One rocprofv3 counter pass per quoted argument over a short timing run; development aid.
+# usage: [RT_HOTPATH_LIB=...] tools/pmc_pass.sh <pipeline> <limit> "<counters pass 1>" "<counters pass 2>" ...
 cd /tmp && export TMPDIR=/tmp
 pipe=$1; limit=$2; shift 2
 i=0
