@@ -106,17 +106,21 @@ int flatten_nodes(const uint32_t *words, size_t n_words, size_t n_ref, const flo
     if (n_words == 0) return RT_OK;
     if (n_words < 2) return fail(RT_ESCENE, "node buffer has %zu words; a node needs at least 2", n_words);
     struct Item { uint32_t word, depth; };
+    const uint32_t HOLE = 0xFFFFFFFFu;
     std::vector<Item> items;        // items[i] describes out[i]; processed in order = breadth-first
-    const size_t max_records = n_words;   // a tree cannot hold more nodes than words
+    const size_t max_nodes = n_words;     // a tree cannot hold more nodes than words
+    size_t n_nodes = 0;
     auto add = [&](uint32_t word, uint32_t depth, const float lo[3], const float hi[3]) {
         RtNodeRec r{};
         for (int k = 0; k < 3; k++) { r.lo[k] = lo[k]; r.hi[k] = hi[k]; r.mid[k] = (hi[k] + lo[k]) / 2.0f; }   // frag:487
         out.push_back(r);
         items.push_back({word, depth});
+        n_nodes++;
     };
     add(0u, 0u, lo0, hi0);
     for (size_t i = 0; i < out.size(); i++) {
         const Item it = items[i];
+        if (it.word == HOLE) continue;
         if ((size_t)it.word + 2 > n_words) return fail(RT_ESCENE, "node at word %u runs past the node buffer (%zu words)", it.word, n_words);
         const uint32_t info = words[it.word], tri_start = words[it.word + 1];
         const uint32_t child_count = info & 0xFu, mask = (info >> 8) & 0xFFu, tri_count = info >> 16;
@@ -126,15 +130,16 @@ int flatten_nodes(const uint32_t *words, size_t n_words, size_t n_ref, const flo
         if ((size_t)tri_start + tri_count > n_ref) return fail(RT_ESCENE, "node at word %u: triangle range [%u,%u) exceeds %zu references", it.word, tri_start, tri_start + tri_count, n_ref);
         if (it.depth > max_depth) max_depth = it.depth;
         if (child_count && it.depth + 1 > RT_MAX_TREE_DEPTH) return fail(RT_ESCENE, "octree deeper than %u levels (or cyclic)", RT_MAX_TREE_DEPTH);
-        if (out.size() + child_count > max_records) return fail(RT_ESCENE, "node buffer describes more than %zu nodes (shared or cyclic children)", max_records);
+        if (n_nodes + child_count > max_nodes) return fail(RT_ESCENE, "node buffer describes more than %zu nodes (shared or cyclic children)", max_nodes);
+        if (child_count && out.size() + 8 > RT_MAX_NODE_RECORDS) return fail(RT_ELIMIT, "octree needs more than %u node records", RT_MAX_NODE_RECORDS);
         float lo[3], hi[3], mid[3];
         for (int k = 0; k < 3; k++) { lo[k] = out[i].lo[k]; hi[k] = out[i].hi[k]; mid[k] = out[i].mid[k]; }
         out[i].info = info;
         out[i].tri_start = tri_start;
         out[i].first_child = (uint32_t)out.size();
         uint32_t ci = 0;
-        for (int o = 0; o < 8; o++) {
-            if (!(mask & (1u << o))) continue;
+        for (int o = 0; o < 8 && child_count; o++) {
+            if (!(mask & (1u << o))) { out.push_back(RtNodeRec{}); items.push_back({HOLE, 0u}); continue; }   // slot of a child that does not exist
             const uint32_t cw = words[it.word + 2 + ci++];
             float clo[3], chi[3];
             for (int k = 0; k < 3; k++) {   // frag:491-500

@@ -6,16 +6,16 @@
 #include "../../include/rt_hotpath.h"
 
 // One octree node as the device sees it: a single 64-byte line holding everything a visit needs -- header,
-// triangle range, the record index of its first child and the node's own box with its midpoint, from which child
-// boxes are derived by midpoint split exactly as the reference shader does (ray_tracer.frag:487-500; the midpoint
-// (max+min)/2 is computed on the host with the same two IEEE operations).  Records are numbered breadth-first and
-// the existing children of a node are consecutive, in ascending octant order: the child in octant o is record
-// first_child + popcount(child_mask & ((1 << o) - 1)).  Built from the reference node words (Octree.cpp:44-75) by
-// rt_scene_create.
+// triangle range, the record index of its block of children and the node's own box with its midpoint, from which
+// child boxes are derived by midpoint split exactly as the reference shader does (ray_tracer.frag:487-500; the midpoint
+// (max+min)/2 is computed on the host with the same two IEEE operations).  Records are laid out breadth-first; a node
+// with children owns a block of eight consecutive records, the child in octant o being record first_child + o (the
+// slots of children that do not exist are never read), so a visit turns "octant passes the slab test" into a record
+// index without counting mask bits.  Built from the reference node words (Octree.cpp:44-75) by rt_scene_create.
 struct alignas(64) RtNodeRec {
     uint32_t info;        // tri_count << 16 | child_mask << 8 | child_count  (reference word 0)
     uint32_t tri_start;   // reference word 1
-    uint32_t first_child; // record index of the first existing child (undefined when child_count == 0)
+    uint32_t first_child; // record index of the child in octant 0 (undefined when child_count == 0)
     uint32_t reserved;
     float lo[3];
     float mid[3];

@@ -393,34 +393,33 @@ DEVI float ray_triangle(const Ray &r, const TriData &d) {
 // pushes the children whose boxes pass the slab test in ascending octant order and the next visit pops the top, so the
 // passing children of a node are visited in descending octant order, each with its whole subtree, before the
 // node's siblings.  That order is reproduced with ONE entry per tree level instead of one per pending node: an entry
-// holds the record index of the node's first child and the set of passing children still to visit, as a bitmask
-// over their ranks among the existing children (entry = first_child | rank_mask << 24).  The slab tests happen, as
+// holds the record index of the node's block of children and the set of passing children still to visit, as a
+// bitmask over octants (entry = first_child | octant_mask << 24; child o is record first_child + o).  The slab tests happen, as
 // in the reference, when the parent is visited -- against the closest distance known at that moment -- and are
 // never repeated.  The stack is a column of LDS: entry k of thread t lives at lds[k * 256 + t] (no bank conflicts
 // whatever the lanes' depths), and it can never hold more than one entry per tree level.
 struct LevelStack {
     uint32_t *col;   // &lds[threadIdx.x]
     int sp;
-    DEVI void reset_to_root() { col[0] = 0u | (1u << 24); sp = 1; }   // the root is rank 0 of a virtual level
+    DEVI void reset_to_root() { col[0] = 0u | (1u << 24); sp = 1; }   // the root is octant 0 of a virtual level
     DEVI bool empty() const { return sp == 0; }
     DEVI uint32_t pop_node() {
         const uint32_t e = col[(sp - 1) * 256];
         const uint32_t mask = e >> 24;
-        const uint32_t r = 31u - (uint32_t)__clz((int)mask);      // highest pending rank = highest octant
+        const uint32_t r = 31u - (uint32_t)__clz((int)mask);      // highest pending octant
         const uint32_t rest = mask & ~(1u << r);
         if (rest) col[(sp - 1) * 256] = (e & 0x00FFFFFFu) | (rest << 24);
         else sp--;
         return (e & 0x00FFFFFFu) + r;
     }
-    DEVI void push_level(uint32_t first_child, uint32_t rank_mask) { col[sp * 256] = first_child | (rank_mask << 24); sp++; }
+    DEVI void push_level(uint32_t first_child, uint32_t octant_mask) { col[sp * 256] = first_child | (octant_mask << 24); sp++; }
 };
 
 // Slab tests of the up-to-eight child boxes of a node (frag:489-513).  The eight boxes only use three plane
 // positions per axis (lo, mid, hi), so the reference's per-child (bound - origin) * inverse_direction products and
 // their min/max are computed once per plane pair and shared: every value is produced by the same operation on the same
-// operands as in the reference, only not recomputed.  Returns the passing children as a bitmask over their RANKS among
-// the existing children (child_mask), in ascending octant order.
-DEVI uint32_t child_pass_ranks(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest) {
+// operands as in the reference, only not recomputed.  Returns the existing children that pass as a bitmask over octants.
+DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest) {
     const f3 tl = (lo - r.pos) * r.inv, tm = (mid - r.pos) * r.inv, th = (hi - r.pos) * r.inv;
     // lower half of an axis: box [lo, mid] -> t1 = tl, t2 = tm; upper half: box [mid, hi] -> t1 = tm, t2 = th
     const f3 near0 = F3(fminf(tl.x, tm.x), fminf(tl.y, tm.y), fminf(tl.z, tm.z)), far0 = F3(fmaxf(tl.x, tm.x), fmaxf(tl.y, tm.y), fmaxf(tl.z, tm.z));
@@ -433,13 +432,7 @@ DEVI uint32_t child_pass_ranks(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t chil
         const float tmin = fmaxf(fmaxf(nx, ny), nz), tmax = fminf(fminf(fx, fy), fz);
         if (tmax > 0.0f && tmin < tmax && tmin < closest) oct_pass |= 1u << i;
     }
-    oct_pass &= child_mask;
-    // octant bits -> rank bits: rank of octant o = popcount(child_mask below o)
-    uint32_t ranks = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (oct_pass & (1u << i)) ranks |= 1u << __popc(child_mask & ((1u << i) - 1u));
-    return ranks;
+    return oct_pass & child_mask;
 }
 
 struct NodeData { uint32_t tri_start, tri_count, child_mask, first_child; f3 lo, mid, hi; };
@@ -476,7 +469,7 @@ DEVI void visit_node(const RtDeviceScene &S, const Ray &r, LevelStack &st, float
         }
     }
     if (n.child_mask == 0) return;
-    const uint32_t pass = child_pass_ranks(r, n.lo, n.mid, n.hi, n.child_mask, closest);
+    const uint32_t pass = child_pass_octants(r, n.lo, n.mid, n.hi, n.child_mask, closest);
     if (pass) st.push_level(n.first_child, pass);
 }
 
