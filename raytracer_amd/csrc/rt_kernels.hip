@@ -507,19 +507,35 @@ DEVI float ray_cylinder(const Ray &r, float closest, f3 &normal) {
     return __builtin_inff();
 }
 
+// The part of RayPortal that does not depend on the ray (frag:331-337): the rectangle's in-plane axes.  Computed once
+// per workgroup with the same operations every fragment would repeat, and kept in LDS.
+struct PortalBasis { float rx, ry, rz, ux, uy, uz; uint32_t ok, pad; };
+DEVI PortalBasis portal_basis(f3 pn) {
+    PortalBasis b;
+    f3 right = cross3(pn, F3(0.0f, 1.0f, 0.0f));
+    b.ok = length3(right) <= 0.0001f ? 0u : 1u;
+    right = normalize3(right);
+    const f3 up = normalize3(cross3(right, pn));
+    b.rx = right.x; b.ry = right.y; b.rz = right.z; b.ux = up.x; b.uy = up.y; b.uz = up.z; b.pad = 0u;
+    return b;
+}
+DEVI void stage_portals(PortalBasis *lds2, const rt_uniforms &U) {
+    if (threadIdx.x < 2) {
+        const float *d = threadIdx.x == 0 ? U.portal_direction_1 : U.portal_direction_2;
+        lds2[threadIdx.x] = portal_basis(F3(d[0], d[1], d[2]));
+    }
+    __syncthreads();
+}
 // frag:320-350
-DEVI float ray_portal(const Ray &r, f3 ppos, f3 pn, float pw, float ph, float closest) {
+DEVI float ray_portal(const Ray &r, f3 ppos, f3 pn, const PortalBasis &pb, float pw, float ph, float closest) {
     const float d = dot3(pn, r.dir);
     if (__builtin_fabsf(d) <= 0.0001f) return __builtin_inff();
     const float t = div_ieee(dot3(ppos - r.pos, pn), d);
     if (t < 0.0f || t > closest) return __builtin_inff();
     const f3 ip = r.pos + r.dir * t;
-    f3 right = cross3(pn, F3(0.0f, 1.0f, 0.0f));
-    if (length3(right) <= 0.0001f) return __builtin_inff();
-    right = normalize3(right);
-    const f3 up = normalize3(cross3(right, pn));
+    if (!pb.ok) return __builtin_inff();
     const f3 c = ip - ppos;
-    if (__builtin_fabsf(dot3(right, c)) < 0.5f * pw && __builtin_fabsf(dot3(up, c)) < 0.5f * ph) return t;
+    if (__builtin_fabsf(dot3(F3(pb.rx, pb.ry, pb.rz), c)) < 0.5f * pw && __builtin_fabsf(dot3(F3(pb.ux, pb.uy, pb.uz), c)) < 0.5f * ph) return t;
     return __builtin_inff();
 }
 
@@ -541,19 +557,27 @@ DEVI f3 barycentric(f3 p, f3 a, f3 b, f3 c) {
 
 // Everything of FindIntersection after the octree loop (frag:517-562): cylinder, portals, hit assembly.
 template <bool COUNT>
-DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const Ray &r, float closest, uint32_t closest_i, uint32_t closest_tri, bool tri_hit,
-                             PrimaryTap *tap, Counters &cn) {
+DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const PortalBasis *portals, const Ray &r, float closest, uint32_t closest_i, uint32_t closest_tri,
+                             bool tri_hit, PrimaryTap *tap, Counters &cn) {
     bool cyl_hit = false;
     f3 cyl_n = F3(0.0f, 0.0f, 0.0f);
+#ifdef EXP_SKIP_CYL
+    const float cyl_t = __builtin_inff();
+#else
     const float cyl_t = ray_cylinder(r, closest, cyl_n);
+#endif
     if (!is_inf(cyl_t)) { cyl_hit = true; closest = cyl_t; }
 
     const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
     const f3 pd1 = F3(U.portal_direction_1[0], U.portal_direction_1[1], U.portal_direction_1[2]);
     const f3 pp2 = F3(U.portal_position_2[0], U.portal_position_2[1], U.portal_position_2[2]);
     const f3 pd2 = F3(U.portal_direction_2[0], U.portal_direction_2[1], U.portal_direction_2[2]);
-    const float p1 = ray_portal(r, pp1, pd1, U.portal_width, U.portal_height, closest);
-    const float p2 = ray_portal(r, pp2, pd2, U.portal_width, U.portal_height, closest);
+#ifdef EXP_SKIP_PORTALS
+    const float p1 = __builtin_inff(), p2 = __builtin_inff();
+#else
+    const float p1 = ray_portal(r, pp1, pd1, portals[0], U.portal_width, U.portal_height, closest);
+    const float p2 = ray_portal(r, pp2, pd2, portals[1], U.portal_width, U.portal_height, closest);
+#endif
 
     Hit h;
     h.has_hit = false; h.position = F3(0, 0, 0); h.normal = F3(0, 0, 0); h.material_id = 0; h.portal_id = 0;
@@ -606,6 +630,9 @@ DEVI int cvt_rne_x86(float f) {
 }
 DEVI float x86_nan(float v) { return v != v ? u2f(0xffc00000u) : v; }
 DEVI f3 sample_sky(const RtDeviceScene &S, f3 d) {
+#ifdef EXP_SKIP_SKY
+    return F3(0.5f, 0.5f, 0.5f);
+#endif
     if (!S.sky) return F3(0.0f, 0.0f, 0.0f);
     d = F3(x86_nan(d.x), x86_nan(d.y), x86_nan(d.z));
     const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
@@ -675,6 +702,9 @@ DEVI float first_hit_depth(const rt_uniforms &U, const Hit &h, const Ray &ray) {
 
 // One iteration of the path loop after the intersection (frag:583-659) for a hit: updates ray, colour and seed.
 DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed &seed) {
+#ifdef EXP_SKIP_SCATTER
+    ray.pos = h.position + h.normal * 0.001f; ray.dir = reflect3(ray.dir, h.normal); return;
+#endif
     if (h.portal_id != 0) {
         const bool one = h.portal_id == 1;
         const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
@@ -733,6 +763,9 @@ DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed 
 
 // frag:667-668
 DEVI f3 tonemap(f3 color) {
+#ifdef EXP_SKIP_TONEMAP
+    return color;
+#endif
     float c[3] = {color.x, color.y, color.z};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -843,7 +876,9 @@ template <int LEVELS, bool COUNT>
 __global__ __launch_bounds__(256) RENDER_OCCUPANCY void render_kernel(RtDeviceScene S, RtLaunch L) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
     __shared__ SphereLds lds_sph;
+    __shared__ PortalBasis lds_portals[2];
     stage_spheres(&lds_sph, c_spheres);
+    stage_portals(lds_portals, L.u);
     LevelStack st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
@@ -858,10 +893,14 @@ __global__ __launch_bounds__(256) RENDER_OCCUPANCY void render_kernel(RtDeviceSc
         ray.pos = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]);
         generate_ray(L.u, nx, ny, ray.dir, seed.base);
         ray.inv = rcp3(ray.dir);
-        float depth = 1.0f;
         f3 color = F3(1.0f, 1.0f, 1.0f);
         uint32_t nrays = 0;
-        PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
+        if (L.u.max_recursion_limit == 0) {   // no segment at all: the planes of the first segment keep their initial values
+            if (L.depth) L.depth[p.pi] = 1.0f;
+            if (L.hit_kind) L.hit_kind[p.pi] = RT_HIT_MISS;
+            if (L.hit_slot) L.hit_slot[p.pi] = 0;
+            if (L.hit_t) L.hit_t[p.pi] = __builtin_inff();
+        }
         for (uint32_t i = 0; i < L.u.max_recursion_limit; i++) {
             float closest = __builtin_inff();
             uint32_t closest_i = 0, closest_tri = 0;
@@ -873,18 +912,20 @@ __global__ __launch_bounds__(256) RENDER_OCCUPANCY void render_kernel(RtDeviceSc
                 st.reset_to_root();
                 while (!st.empty()) visit_node<COUNT>(S, ray, st, closest, closest_tri, tri_hit, cn);
             }
-            const Hit h = finish_intersection<COUNT>(S, L.u, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
+            PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
+            const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
             nrays++;
-            if (i == 0) depth = first_hit_depth(L.u, h, ray);
+            if (i == 0) {   // the first segment's planes are stored at once instead of being carried through the path
+                if (L.depth) L.depth[p.pi] = first_hit_depth(L.u, h, ray);
+                if (L.hit_kind) L.hit_kind[p.pi] = tap.kind;
+                if (L.hit_slot) L.hit_slot[p.pi] = tap.slot;
+                if (L.hit_t) L.hit_t[p.pi] = tap.t;
+            }
             if (!h.has_hit) { color = color * sample_sky(S, ray.dir); break; }
             scatter(L.u, h, ray, color, seed);
             ray.inv = rcp3(ray.dir);
         }
         write_pixel(L, p.pi, tonemap(color));
-        if (L.depth) L.depth[p.pi] = depth;
-        if (L.hit_kind) L.hit_kind[p.pi] = tap.kind;
-        if (L.hit_slot) L.hit_slot[p.pi] = tap.slot;
-        if (L.hit_t) L.hit_t[p.pi] = tap.t;
         if (L.n_rays) L.n_rays[p.pi] = nrays;
     }
     if (COUNT && L.counters) flush_counters(L.counters, cn);
@@ -1067,6 +1108,8 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
 template <bool D0, bool COUNT>
 __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles, uint32_t track_alive) {
     __shared__ uint32_t lds4[4];
+    __shared__ PortalBasis lds_portals[2];
+    stage_portals(lds_portals, L.u);
     const uint32_t cur = depth & 1u, nxt = cur ^ 1u;
     const float4 *__restrict__ A = WS.pos_seed[cur];
     const float4 *__restrict__ B = WS.dir_pix[cur];
@@ -1100,7 +1143,7 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
                 const uint32_t tri_word = WS.tri[slot];
                 if (COUNT) cn.rays++;
                 PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
-                const Hit h = finish_intersection<COUNT>(S, L.u, ray, closest, closest_i, tri_word & 0x7FFFFFFFu, (tri_word >> 31) != 0, D0 ? &tap : nullptr, cn);
+                const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, tri_word & 0x7FFFFFFFu, (tri_word >> 31) != 0, D0 ? &tap : nullptr, cn);
                 if (D0) {
                     if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
                     if (L.hit_kind) L.hit_kind[pix] = tap.kind;
@@ -1176,7 +1219,9 @@ template <int LEVELS, bool COUNT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 20 ? PATH_WAVES_PER_SIMD : 3, LEVELS <= 20 ? PATH_WAVES_PER_SIMD : 3))) void path_kernel(RtDeviceScene S, RtLaunch L, uint32_t *pool, uint32_t n_tiles) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
     __shared__ SphereLds lds_sph;
+    __shared__ PortalBasis lds_portals[2];
     stage_spheres(&lds_sph, c_spheres);
+    stage_portals(lds_portals, L.u);
     LevelStack st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
@@ -1220,7 +1265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
         if (work != 0 && (trav == 0 || (uint32_t)__popcll(work) >= refill)) {
             if (has_path && !traversing) {   // the segment's intersection is complete (frag:535-563,575-664)
                 PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
-                const Hit h = finish_intersection<COUNT>(S, L.u, ray, closest, closest_i, closest_tri, tri_hit, seg == 0 ? &tap : nullptr, cn);
+                const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, seg == 0 ? &tap : nullptr, cn);
                 if (seg == 0) {
                     if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
                     if (L.hit_kind) L.hit_kind[pix] = tap.kind;
