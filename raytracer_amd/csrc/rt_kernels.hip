@@ -277,7 +277,7 @@ DEVI void sphere_accept(float b, float c, uint32_t i, float &closest, uint32_t &
 // arithmetic, whereas scalar loads from constant memory cannot be waited for individually.
 struct SphereLds { float4 tab[NUM_SPHERES]; SphereGrid grid; };
 DEVI void stage_spheres(SphereLds *lds, const float4 *src) {
-    if (threadIdx.x < NUM_SPHERES) lds->tab[threadIdx.x] = src[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < NUM_SPHERES; i += blockDim.x) lds->tab[i] = src[i];
     uint32_t *dst = reinterpret_cast<uint32_t *>(&lds->grid);
     const uint32_t *g = reinterpret_cast<const uint32_t *>(&c_sphere_grid);
     for (uint32_t i = threadIdx.x; i < sizeof(SphereGrid) / 4u; i += blockDim.x) dst[i] = g[i];
@@ -396,24 +396,26 @@ DEVI float ray_triangle(const Ray &r, const TriData &d) {
 // holds the record index of the node's block of children and the set of passing children still to visit, as a
 // bitmask over octants (entry = first_child | octant_mask << 24; child o is record first_child + o).  The slab tests happen, as
 // in the reference, when the parent is visited -- against the closest distance known at that moment -- and are
-// never repeated.  The stack is a column of LDS: entry k of thread t lives at lds[k * 256 + t] (no bank conflicts
+// never repeated.  The stack is a column of LDS: entry k of thread t lives at lds[k * threads + t] (no bank conflicts
 // whatever the lanes' depths), and it can never hold more than one entry per tree level.
-struct LevelStack {
+template <int STRIDE>   // threads per workgroup = distance in words between two entries of one lane
+struct LevelStackT {
     uint32_t *col;   // &lds[threadIdx.x]
     int sp;
     DEVI void reset_to_root() { col[0] = 0u | (1u << 24); sp = 1; }   // the root is octant 0 of a virtual level
     DEVI bool empty() const { return sp == 0; }
     DEVI uint32_t pop_node() {
-        const uint32_t e = col[(sp - 1) * 256];
+        const uint32_t e = col[(sp - 1) * STRIDE];
         const uint32_t mask = e >> 24;
         const uint32_t r = 31u - (uint32_t)__clz((int)mask);      // highest pending octant
         const uint32_t rest = mask & ~(1u << r);
-        if (rest) col[(sp - 1) * 256] = (e & 0x00FFFFFFu) | (rest << 24);
+        if (rest) col[(sp - 1) * STRIDE] = (e & 0x00FFFFFFu) | (rest << 24);
         else sp--;
         return (e & 0x00FFFFFFu) + r;
     }
-    DEVI void push_level(uint32_t first_child, uint32_t octant_mask) { col[sp * 256] = first_child | (octant_mask << 24); sp++; }
+    DEVI void push_level(uint32_t first_child, uint32_t octant_mask) { col[sp * STRIDE] = first_child | (octant_mask << 24); sp++; }
 };
+typedef LevelStackT<256> LevelStack;
 
 // Slab tests of the up-to-eight child boxes of a node (frag:489-513).  The eight boxes only use three plane
 // positions per axis (lo, mid, hi), so the reference's per-child (bound - origin) * inverse_direction products and
@@ -451,8 +453,8 @@ DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
 #define TRI_BATCH 2u   // more in flight costs registers, and with them resident waves
 #endif
 // One visit (frag:456-513) by a single lane: test the node's triangles in order, then the boxes of its children.
-template <bool COUNT>
-DEVI void visit_node(const RtDeviceScene &S, const Ray &r, LevelStack &st, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
+template <bool COUNT, class STACK>
+DEVI void visit_node(const RtDeviceScene &S, const Ray &r, STACK &st, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
     const NodeData n = load_node(S, st.pop_node());
     if (COUNT) { cn.pops++; cn.tri_tests += n.tri_count; cn.box_tests += __popc(n.child_mask); }
     // triangle records are fetched TRI_BATCH at a time so that their memory latencies overlap; they are tested in order
@@ -810,12 +812,18 @@ DEVI PixelId pixel_of_tile(const RtLaunch &L, uint32_t tile_x, uint32_t tile_y, 
     p.pi = L.compact_rows ? (size_t)part_lr * L.width + p.x : p.fi;
     return p;
 }
-DEVI PixelId pixel_of(const RtLaunch &L, uint32_t bid_raw, uint32_t tid) {
+// Workgroups are dealt to the 8 XCDs round-robin by their index; this renumbering (a bijection on [0, n)) gives each
+// XCD (index % 8) a contiguous range, so that neighbouring pieces of the frame share an L2.
+DEVI uint32_t xcd_contiguous(uint32_t raw, uint32_t n) {
+    const uint32_t q = n / 8u, rem = n % 8u, cls = raw % 8u, idx = raw / 8u;
+    return (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;
+}
+// Pixel of thread `tid` of workgroup `wg_raw` when every 16x16 tile is shared by `per_tile` workgroups of 256 / per_tile threads.
+DEVI PixelId pixel_of(const RtLaunch &L, uint32_t wg_raw, uint32_t tid, uint32_t per_tile = 1u) {
     const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
-    const uint32_t nwg = tiles_x * tiles_y;
-    const uint32_t q = nwg / 8u, rem = nwg % 8u, cls = bid_raw % 8u, idx = bid_raw / 8u;
-    const uint32_t bid = (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;   // bijective
-    return pixel_of_tile(L, bid % tiles_x, bid / tiles_x, tid);
+    const uint32_t v = xcd_contiguous(wg_raw, tiles_x * tiles_y * per_tile);
+    const uint32_t tile = v / per_tile;
+    return pixel_of_tile(L, tile % tiles_x, tile / tiles_x, (v % per_tile) * (256u / per_tile) + tid);
 }
 // Tile order of the persistent path kernel: the tiles of the rectangle L.hot (where the octree projects to: the
 // pixels whose paths can be long) come first, then the rows below it, the rows above it, and the tiles left and right
@@ -866,23 +874,27 @@ DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
 // ================================================================================================
 // Resident waves per SIMD the register allocator must make room for.  The kernel hides the latency of its dependent
 // node and triangle loads only through other waves, so six waves with a few spilled registers beat four without
-// (measured: 1.10 vs 1.24 ms per 4K frame); six is also what the LDS stack allows (6 workgroups x 23 KB per CU).
+// (measured: 1.10 vs 1.24 ms per 4K frame); six is also what the LDS allows (a 20-level stack is 80 bytes per lane,
+// plus 3.2 KB of sphere data per workgroup: twelve 128-thread workgroups per CU).
 #ifndef RENDER_WAVES_PER_SIMD
 #define RENDER_WAVES_PER_SIMD 6
 #endif
 // (the variant for very deep trees needs 46 KB of LDS per workgroup: three fit, so it keeps its registers)
 #define RENDER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3, LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3)))
-template <int LEVELS, bool COUNT>
-__global__ __launch_bounds__(256) RENDER_OCCUPANCY void render_kernel(RtDeviceScene S, RtLaunch L) {
-    __shared__ uint32_t lds_stack[LEVELS * 256];
+#ifndef RENDER_BLOCK
+#define RENDER_BLOCK 128   // threads per workgroup: a workgroup keeps its LDS until its slowest wave ends, so small ones free the CU sooner
+#endif
+template <int LEVELS, bool COUNT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDeviceScene S, RtLaunch L) {
+    __shared__ uint32_t lds_stack[LEVELS * BLOCK];
     __shared__ SphereLds lds_sph;
     __shared__ PortalBasis lds_portals[2];
     stage_spheres(&lds_sph, c_spheres);
     stage_portals(lds_portals, L.u);
-    LevelStack st;
+    LevelStackT<BLOCK> st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
-    const PixelId p = pixel_of(L, blockIdx.x, threadIdx.x);
+    const PixelId p = pixel_of(L, blockIdx.x, threadIdx.x, 256u / BLOCK);
     Counters cn = {0, 0, 0, 0, 0, 0};
     if (p.active) {
         float nx, ny;
@@ -1361,8 +1373,9 @@ void launch_path(const RtDeviceScene &S, const RtLaunch &L, uint32_t *pool, uint
 
 template <int LEVELS>
 int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid) {
-    if (L.counters) hipLaunchKernelGGL((render_kernel<LEVELS, true>), grid, dim3(256), 0, st, S, L);
-    else hipLaunchKernelGGL((render_kernel<LEVELS, false>), grid, dim3(256), 0, st, S, L);
+    grid.x *= 256u / RENDER_BLOCK;
+    if (L.counters) hipLaunchKernelGGL((render_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L);
+    else hipLaunchKernelGGL((render_kernel<LEVELS, false, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L);
     return (int)hipGetLastError();
 }
 
