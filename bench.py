@@ -12,7 +12,8 @@ App::Render does (time advances by 1/60 s per frame).  One step = one frame.  Me
 FindIntersection call (path segment); rays are COUNTED by replaying the timed frames with the library's work counters on.
 
 N > 1: the frame is sharded by interleaved 16-row strips over the ranks (strong scaling), the scene is broadcast from
-rank 0 and every frame's bands are gathered to rank 0 with RCCL inside the timed region.
+rank 0 and every frame's bands are gathered to rank 0 with RCCL inside the timed region (the gather of frame k runs on a
+side stream while frame k+1 renders; the last gather is waited for before the clock stops).
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -90,10 +91,18 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-tracing pass has no CPU fallback")
+    # RT_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend -- a functional rehearsal of the N > 1 path on a
+    # one-GPU box (RCCL does not accept two ranks on one device); never a measurement
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     # ---- scene (built on rank 0 with the host-side builders, broadcast over RCCL) -------------------------------
     t_build = time.time()
@@ -135,6 +144,8 @@ def main():
     def render(step, accum_index, sync=False):
         sc.render_raw(frame_of(step, accum_index), target_of(sync))
 
+    gatherer = rdist.FrameGatherer(H, BAND_ROWS) if world > 1 else None
+
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
@@ -153,7 +164,9 @@ def main():
             for fr in frames:
                 sc.render_raw(fr, target_of())
                 if world > 1:
-                    rdist.gather_frame(color, H, BAND_ROWS)
+                    gatherer.submit(color)
+            if world > 1:
+                gatherer.last()
 
     # the per-frame inputs (camera matrices, time) are prepared before the clock starts: they are the caller's data
     warm_frames = [frame_of(k, k + 1) for k in range(args.warmup)]
@@ -201,7 +214,7 @@ def main():
         "metric": "Mrays/s (primary+secondary) & frame ms at 4K, 1/2/4/8 MI355X vs llvmpipe CPU",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic camera/skybox; bundled bunny mesh (default scene's dragon is absent from the reference checkout)",
+        "vs_baseline": None, "dtype": "f32", "data": ("REHEARSAL on one GPU, not a measurement; " if rehearse else "") + "synthetic camera/skybox; bundled bunny mesh (default scene's dragon is absent from the reference checkout)",
         "config": {"workload": f"{args.scene} default-style scene {W}x{H}, max_recursion_limit={args.max_recursion_limit} (primary + one secondary segment), 1 spp/frame, progressive accumulation",
                    "width": W, "height": H, "max_recursion_limit": args.max_recursion_limit, "band_rows": BAND_ROWS,
                    "parallelism": f"interleaved row bands x{world}" + (" + RCCL gather per frame" if world > 1 else "")},
@@ -225,7 +238,7 @@ def main():
                        "note": "octree traversal is bound by dependent-load latency and VALU issue, not by HBM bandwidth: see valu and DESIGN.md"}
     aflops = algorithmic_flops(local_work) / args.steps
     frame_ms = 1e3 * elapsed / args.steps
-    out["valu"] = {"scope": "whole frame", "achieved_tflops": round(aflops / (frame_ms * 1e-3) / 1e12, 3), "peak_tflops_no_fma": VALU_PEAK_TFLOPS_NO_FMA,
+    out["valu"] = {"scope": "whole frame" if world == 1 else "rank 0's share of the frame", "achieved_tflops": round(aflops / (frame_ms * 1e-3) / 1e12, 3), "peak_tflops_no_fma": VALU_PEAK_TFLOPS_NO_FMA,
                    "frac": round(aflops / (frame_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS_NO_FMA, 4), "algorithmic_flop_per_frame": int(aflops)}
 
     # ---- CPU baseline: the oracle (a port of the shader with the reference vehicle's numerics) on this host -----

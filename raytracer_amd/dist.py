@@ -9,7 +9,8 @@ accumulation stays local to the band.  Two collectives exist, both outside the p
   broadcast_scene   once per scene: the four scene arrays, bounds and the skybox from rank 0
   gather_frame      once per presented frame: every rank's compact band buffer to rank 0, which re-interleaves them
 
-The functions work on any backend/device, which is how the logic is tested on CPU with gloo.
+The functions work on any backend/device, which is how the logic is tested on CPU with gloo; with gloo and device
+tensors the payload is staged through host memory (gloo has no device gather).
 """
 from __future__ import annotations
 
@@ -63,7 +64,12 @@ def broadcast_scene(arrays: dict | None, device: torch.device, src: int = 0) -> 
         else:
             buf = torch.empty(max(nbytes, 0), dtype=torch.uint8, device=device)
         if nbytes:
-            dist.broadcast(buf, src=src)
+            if dist.get_backend() == "gloo" and buf.is_cuda:
+                host = buf.cpu()
+                dist.broadcast(host, src=src)
+                buf = host
+            else:
+                dist.broadcast(buf, src=src)
         out[k] = buf.cpu().numpy().view(dtypes[k]).reshape(shape)
     return out
 
@@ -74,8 +80,15 @@ def gather_frame(local: torch.Tensor, height: int, band_rows: int, dst: int = 0)
     parts, rank = dist.get_world_size(), dist.get_rank()
     pad = padded_row_count(height, band_rows, parts)
     assert local.shape[0] == pad, (local.shape, pad)
-    bufs = [torch.empty_like(local) for _ in range(parts)] if rank == dst else None
-    dist.gather(local, bufs, dst=dst)
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        host = local.cpu()
+        bufs = [torch.empty_like(host) for _ in range(parts)] if rank == dst else None
+        dist.gather(host, bufs, dst=dst)
+        if rank == dst:
+            bufs = [b.to(local.device) for b in bufs]
+    else:
+        bufs = [torch.empty_like(local) for _ in range(parts)] if rank == dst else None
+        dist.gather(local, bufs, dst=dst)
     if rank != dst:
         return None
     # [part, strip_local, band_rows, W, C] -> [strip_local, part, band_rows, W, C] -> rows in frame order
@@ -84,3 +97,42 @@ def gather_frame(local: torch.Tensor, height: int, band_rows: int, dst: int = 0)
     s_local = pad // band_rows
     frame = stack.view(parts, s_local, band_rows, w, c).permute(1, 0, 2, 3, 4).reshape(s_local * parts * band_rows, w, c)
     return frame[:height].contiguous()
+
+
+class FrameGatherer:
+    """Gathers every frame's bands to rank `dst` while the next frame is already being rendered.
+
+    submit(local) snapshots the rank's compact band buffer on the caller's current stream (a device-to-device copy;
+    the renderer keeps accumulating into `local`) and runs gather_frame on the snapshot on a side stream; the next
+    submit first waits until the previous gather has consumed the snapshot.  last() waits for the gather in flight and
+    returns the newest gathered frame on `dst` (None elsewhere).  On CPU tensors everything is synchronous."""
+
+    def __init__(self, height: int, band_rows: int, dst: int = 0):
+        self.height, self.band_rows, self.dst = height, band_rows, dst
+        self.snap = None
+        self.frame = None
+        self.side = None
+        self.done = None
+
+    def submit(self, local: torch.Tensor):
+        if not local.is_cuda:
+            self.frame = gather_frame(local, self.height, self.band_rows, self.dst)
+            return
+        if self.snap is None:
+            self.snap = torch.empty_like(local)
+            self.side = torch.cuda.Stream(device=local.device)
+            self.done = torch.cuda.Event()
+        main = torch.cuda.current_stream(local.device)
+        main.wait_event(self.done)          # the previous gather has read the snapshot (no-op the first time)
+        self.snap.copy_(local)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self.side.wait_event(ready)
+        with torch.cuda.stream(self.side):
+            self.frame = gather_frame(self.snap, self.height, self.band_rows, self.dst)
+            self.done.record(self.side)
+
+    def last(self):
+        if self.side is not None:
+            self.side.synchronize()
+        return self.frame

@@ -82,3 +82,42 @@ def test_band_row_count_matches_library():
         for p in range(parts):
             fr = api.make_frame(u, 64, height, band=(band_rows, parts, p))
             assert api.band_row_count(fr) == rdist.local_row_count(height, band_rows, parts, p)
+
+
+def _gatherer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracer_amd import dist as rdist
+    h, w, rows = 100, 8, 16
+    pad = rdist.padded_row_count(h, rows, world)
+    g = rdist.FrameGatherer(h, rows)
+    ok = True
+    for k in range(3):
+        local = torch.full((pad, w, 4), -1.0)
+        ys = rdist.local_to_frame_rows(h, rows, world, rank)
+        for lr, y in enumerate(ys):
+            if y >= 0:
+                local[lr] = float(1000 * k + y)
+        g.submit(local)
+        frame = g.last()
+        if rank == 0:
+            ok = ok and bool((frame[:, 0, 0] == torch.arange(h, dtype=torch.float32) + 1000 * k).all())
+        else:
+            ok = ok and frame is None
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_frame_gatherer_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    ps = [ctx.Process(target=_gatherer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == {0: True, 1: True}
