@@ -563,23 +563,15 @@ DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const
                              bool tri_hit, PrimaryTap *tap, Counters &cn) {
     bool cyl_hit = false;
     f3 cyl_n = F3(0.0f, 0.0f, 0.0f);
-#ifdef EXP_SKIP_CYL
-    const float cyl_t = __builtin_inff();
-#else
     const float cyl_t = ray_cylinder(r, closest, cyl_n);
-#endif
     if (!is_inf(cyl_t)) { cyl_hit = true; closest = cyl_t; }
 
     const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
     const f3 pd1 = F3(U.portal_direction_1[0], U.portal_direction_1[1], U.portal_direction_1[2]);
     const f3 pp2 = F3(U.portal_position_2[0], U.portal_position_2[1], U.portal_position_2[2]);
     const f3 pd2 = F3(U.portal_direction_2[0], U.portal_direction_2[1], U.portal_direction_2[2]);
-#ifdef EXP_SKIP_PORTALS
-    const float p1 = __builtin_inff(), p2 = __builtin_inff();
-#else
     const float p1 = ray_portal(r, pp1, pd1, portals[0], U.portal_width, U.portal_height, closest);
     const float p2 = ray_portal(r, pp2, pd2, portals[1], U.portal_width, U.portal_height, closest);
-#endif
 
     Hit h;
     h.has_hit = false; h.position = F3(0, 0, 0); h.normal = F3(0, 0, 0); h.material_id = 0; h.portal_id = 0;
@@ -632,9 +624,6 @@ DEVI int cvt_rne_x86(float f) {
 }
 DEVI float x86_nan(float v) { return v != v ? u2f(0xffc00000u) : v; }
 DEVI f3 sample_sky(const RtDeviceScene &S, f3 d) {
-#ifdef EXP_SKIP_SKY
-    return F3(0.5f, 0.5f, 0.5f);
-#endif
     if (!S.sky) return F3(0.0f, 0.0f, 0.0f);
     d = F3(x86_nan(d.x), x86_nan(d.y), x86_nan(d.z));
     const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
@@ -704,9 +693,6 @@ DEVI float first_hit_depth(const rt_uniforms &U, const Hit &h, const Ray &ray) {
 
 // One iteration of the path loop after the intersection (frag:583-659) for a hit: updates ray, colour and seed.
 DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed &seed) {
-#ifdef EXP_SKIP_SCATTER
-    ray.pos = h.position + h.normal * 0.001f; ray.dir = reflect3(ray.dir, h.normal); return;
-#endif
     if (h.portal_id != 0) {
         const bool one = h.portal_id == 1;
         const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
@@ -765,9 +751,6 @@ DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed 
 
 // frag:667-668
 DEVI f3 tonemap(f3 color) {
-#ifdef EXP_SKIP_TONEMAP
-    return color;
-#endif
     float c[3] = {color.x, color.y, color.z};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
