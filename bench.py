@@ -173,8 +173,12 @@ def main():
     timed_frames = [frame_of(k, k + 1) for k in range(args.steps)]
 
     # untimed: lets the library's pipeline selection settle on this workload (it times its own first frames)
-    for k in range(12 if args.pipeline == "auto" else 0):
-        render(k, k + 1, sync=True)
+    if args.pipeline == "auto":
+        for k in range(12):
+            if sequence:
+                sc.render_sequence_raw([frame_of(4 * k + j, j + 1) for j in range(4)], target_of(sync=True))
+            else:
+                render(k, k + 1, sync=True)
     if args.warmup:
         run_steps(warm_frames)
     sync_all()
@@ -235,6 +239,9 @@ def main():
     out["roofline"] = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(kernel), "kernel_ms": round(k_ms, 4),
                        "launches": k_launches, "algorithmic_bytes_per_launch": int(abytes),
+                       "launches_per_frame": k_launches / args.steps,
+                       "device_rate": {"what": "algorithmic bytes of this kernel per frame / frame time (its launches of one frame run concurrently on separate streams)",
+                                       "GB/s": round(total_bytes / max(k_launches, 1) * (k_launches / args.steps) / (1e6 * 1e3 * elapsed / args.steps), 3)},
                        "note": "octree traversal is bound by dependent-load latency and VALU issue, not by HBM bandwidth: see valu and DESIGN.md"}
     aflops = algorithmic_flops(local_work) / args.steps
     frame_ms = 1e3 * elapsed / args.steps

@@ -57,7 +57,7 @@ struct rt_scene {
     // wavefront pipeline: a frame is cut into up to RT_MAX_SUBFRAMES interleaved sub-frames that run as independent
     // kernel chains on their own streams, so that the sparse tail of one chain overlaps the dense kernels of another
     int pipeline = RT_PIPELINE_AUTO;
-    int subframes = 2;
+    int subframes = 3;
     struct Sub {
         RtWorkspace ws{};
         void *block = nullptr;
@@ -500,14 +500,17 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     int pipeline = s->pipeline;
     bool measure = false;
     if (pipeline == RT_PIPELINE_AUTO) {
-        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0);
+        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^ (uint64_t)(n_frames > 1 ? 2 : 0);
         pipeline = tuner_choose(s, key + 1, &measure);
     }
     const bool wavefront = pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
     const bool persistent = pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
     // number of sub-frames: every one should still fill the machine (>= 64 strips of 16 rows x width)
     uint32_t K = 1;
-    if (wavefront || persistent) {
+    // the one-kernel-per-frame pipeline gains from sub-frames only inside a sequence, where the end of one kernel then
+    // overlaps the start of the next; for a single frame the fork and join would cost more
+    const bool megasplit = !wavefront && !persistent && n_frames > 1 && L.n_local_rows > 0;
+    if (wavefront || persistent || megasplit) {
         const uint32_t strips = L.n_local_rows / f->band_rows;
         K = (uint32_t)s->subframes;
         while (K > 1 && (size_t)(strips / K) * f->band_rows * f->width < ((size_t)1 << 19)) K--;
@@ -518,7 +521,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             if (wavefront) {
                 int wrc = ensure_workspace(&s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
                 if (wrc != RT_OK) return wrc;
-            } else if (!s->sub[j].pool) {
+            } else if (persistent && !s->sub[j].pool) {
                 HIP_TRY(hipMalloc((void **)&s->sub[j].pool, rt_pool_bytes()));
             }
             if (K > 1 && !s->sub[j].stream) {
@@ -547,7 +550,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             }
             return Li;
         };
-        if (!wavefront && !persistent) {
+        if (!wavefront && !persistent && K == 1) {
             // one kernel per frame, back to back on one stream: a single event pair around the whole sequence gives the
             // average launch duration without putting a timing event between every two launches
             RtProbe *pr = s->timing && s->sub[0].probe.used < s->sub[0].probe.capacity ? &s->sub[0].probe : nullptr;

@@ -182,7 +182,7 @@ def test_render_sequence_equals_frame_by_frame(bunny_octree, test_sky):
     ref = np.zeros((h, w, 4), np.float32)
     for k in range(n):
         ref = sc.render(us[k], w, h, accum_index=k + 1, color=ref, planes=False)["rgba"]
-    for pipe, sub in (("megakernel", 1), ("wavefront", 1), ("wavefront", 2), ("wavefront", 4), ("persistent", 1), ("persistent", 3)):
+    for pipe, sub in (("megakernel", 1), ("megakernel", 3), ("auto", 3), ("wavefront", 1), ("wavefront", 2), ("wavefront", 4), ("persistent", 1), ("persistent", 3)):
         sc.set_pipeline(pipe)
         sc.set_subframes(sub)
         buf = np.zeros((h, w, 4), np.float32)

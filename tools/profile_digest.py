@@ -26,7 +26,7 @@ traffic = {}
 for k, cs in pmc.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         base = k.split("<")[0]
-        if k.endswith(", true>") and any(o.split("<")[0] == base and not o.endswith(", true>") for o in pmc):
+        if ", true" in k and any(o.split("<")[0] == base and ", true" not in o for o in pmc):
             continue   # the variant with work counters on is not the one that is timed
         # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so it is doubled
         # (exact for wide coalesced reads, an upper bound for this kernel's scattered 64-byte gathers)

@@ -30,7 +30,7 @@ def main():
     for name in a.scenes.split(","):
         d = empty_scene() if name == "empty" else {"bunny": scenes.default_octree, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "small": scenes.small_test_scene}[name]().as_dict()
         sc = api.Scene.from_dict(d); sc.set_skybox(sky)
-        for pipe, lim, sub in [(p, int(x), int(k)) for p in a.pipelines.split(",") for x in a.limits.split(",") for k in (a.subframes.split(",") if p != "megakernel" else ["1"])]:
+        for pipe, lim, sub in [(p, int(x), int(k)) for p in a.pipelines.split(",") for x in a.limits.split(",") for k in a.subframes.split(",")]:
             sc.set_pipeline(pipe); sc.set_subframes(sub)
             host_color = np.zeros((H, W, 4), np.float32)
             def run(k, sync=False):
@@ -44,9 +44,12 @@ def main():
                 if sync is None: return fr, tg
                 sc.render_raw(fr, tg)
             run(0); run(1); torch.cuda.synchronize()
+            seq_frames = [run(k, None)[0] for k in range(a.reps)] if a.sequence and not a.host else None
+            if seq_frames:
+                sc.render_sequence_raw(seq_frames[:2], run(0, None)[1]); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if a.sequence:
-                sc.render_sequence_raw([run(k, None)[0] for k in range(a.reps)], run(0, None)[1])
+            if seq_frames:
+                sc.render_sequence_raw(seq_frames, run(0, None)[1])
             else:
                 for k in range(a.reps): run(k)
             torch.cuda.synchronize()
