@@ -540,7 +540,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             RtLaunch Li = L0;
             Li.u = frames[i].u; Li.accum_index = frames[i].accum_index; Li.blend = frames[i].blend ? 1u : 0u;
             uint32_t rect[4];
-            const bool any = persistent && octree_screen_rect(s->d, frames[i].u, f->width, f->height, rect);
+            const bool any = octree_screen_rect(s->d, frames[i].u, f->width, f->height, rect);
             hot_tiles(rect, any, f->band_rows, f->band_parts * parts, Li.hot);
             if (parts > 1) {
                 rt_frame fj = *f;

