@@ -162,11 +162,11 @@ int rt_scene_set_pipeline(rt_scene *scene, int pipeline);
 /* The pipeline the next frame would run with and, under RT_PIPELINE_AUTO, the per-frame milliseconds measured so far
  * for RT_PIPELINE_MEGAKERNEL / WAVEFRONT / PERSISTENT (index = enum value; negative: not measured yet). */
 int rt_scene_pipeline_state(rt_scene *scene, int *selected, double ms_per_frame[3]);
-/* A frame can be rendered as up to n (1..8, default 3) interleaved sub-frames (every n-th 16-row strip) whose kernels
- * run on separate internal streams, forked from and joined to rt_frame.stream, so that the sparse end of one
- * sub-frame's kernels overlaps dense work of another.  The persistent and wavefront pipelines always do this; the
- * one-kernel-per-frame pipeline does it inside rt_render_sequence, where consecutive frames of a sub-frame follow each
- * other on their own stream without a join.  A sub-frame is never smaller than 2^19 pixels.  Results do not depend on n. */
+/* Persistent and wavefront pipelines: a frame is rendered as up to n (1..8, default 3) interleaved sub-frames (every
+ * n-th 16-row strip) whose kernels run on separate internal streams, forked from and joined to rt_frame.stream, so that
+ * the sparse end of one sub-frame's kernels overlaps dense work of another (most effective inside rt_render_sequence,
+ * where consecutive frames of a sub-frame follow each other without a join).  A sub-frame is never smaller than 2^19
+ * pixels.  Results do not depend on n. */
 int rt_scene_set_subframes(rt_scene *scene, int n);
 int rt_scene_destroy(rt_scene *scene);
 

@@ -66,6 +66,11 @@ struct rt_scene {
         hipEvent_t done = nullptr;
         RtProbe probe{};
         uint32_t *pool = nullptr;   // tile counter of the persistent path kernel
+        // one-lane-per-pixel kernel: per-unit cost measured by the last launch and the start order derived from it
+        uint32_t *lpt_cost = nullptr, *lpt_order = nullptr;
+        size_t lpt_units = 0;
+        uint64_t lpt_key = 0;       // frame geometry the order belongs to (0: none)
+        uint32_t lpt_age = 0;       // launches since the order was last rebuilt
     } sub[RT_MAX_SUBFRAMES];
     bool timing = false;
     hipEvent_t fork_ev = nullptr;
@@ -507,10 +512,9 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     const bool persistent = pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
     // number of sub-frames: every one should still fill the machine (>= 64 strips of 16 rows x width)
     uint32_t K = 1;
-    // the one-kernel-per-frame pipeline gains from sub-frames only inside a sequence, where the end of one kernel then
-    // overlaps the start of the next; for a single frame the fork and join would cost more
-    const bool megasplit = !wavefront && !persistent && n_frames > 1 && L.n_local_rows > 0;
-    if (wavefront || persistent || megasplit) {
+    // (the one-kernel-per-frame pipeline orders its workgroups by measured cost instead, see attach_order: with that its
+    // kernels end without a sparse tail and sub-frames bring it nothing)
+    if (wavefront || persistent) {
         const uint32_t strips = L.n_local_rows / f->band_rows;
         K = (uint32_t)s->subframes;
         while (K > 1 && (size_t)(strips / K) * f->band_rows * f->width < ((size_t)1 << 19)) K--;
@@ -535,6 +539,39 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     // Otherwise K sub-frame chains are forked from the caller's stream once, each runs its share of every frame
     // in order on its own stream (a pixel belongs to one sub-frame, so its accumulation order is kept), and all
     // are joined back once: the chains drift apart and the sparse end of one kernel overlaps dense work of others.
+    // One-lane-per-pixel launches start their workgroups in the order of the cost (duration) that the previous launch with
+    // the same frame geometry measured per workgroup: progressive accumulation renders the same view again and again, and
+    // a moving camera changes the cost map only gradually.  The first launch of a geometry uses the order given by the
+    // octree's screen rectangle.  Every launch leaves its costs, sorted, for the next.
+    auto attach_order = [&](RtLaunch &Li, uint32_t j, const rt_uniforms &u, hipStream_t stream) -> int {
+        rt_scene::Sub &sb = s->sub[j];
+        const size_t units = rt_render_units(Li.width, Li.n_local_rows);
+        if (units == 0) return 0;
+        if (sb.lpt_units != units) {
+            if (sb.lpt_cost) { if (hipDeviceSynchronize() != hipSuccess) return 1; (void)hipFree(sb.lpt_cost); sb.lpt_cost = nullptr; }
+            if (hipMalloc((void **)&sb.lpt_cost, 2 * units * sizeof(uint32_t)) != hipSuccess) { sb.lpt_units = 0; return 1; }
+            sb.lpt_order = sb.lpt_cost + units;
+            sb.lpt_units = units;
+            sb.lpt_key = 0;
+            if (hipMemsetAsync(sb.lpt_cost, 0, units * sizeof(uint32_t), stream) != hipSuccess) return 1;
+        }
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+        (void)u;   // the view is deliberately not part of the key: a camera that moves a little keeps most of the cost map
+        const uint32_t geo[8] = {Li.width, Li.height, Li.band_rows, Li.band_parts, Li.band_part, Li.n_local_rows, Li.compact_rows, (uint32_t)(uintptr_t)stream};
+        mix(geo, sizeof geo);
+        if (h == 0) h = 1;
+        // the cost map changes slowly: the order is rebuilt after the first launch of a geometry and then every eighth
+        // launch (the costs in between accumulate as maxima), which keeps the sort off most frames' critical path
+        const bool known = sb.lpt_key == h;
+        if (!known) sb.lpt_age = 0;
+        Li.cost = sb.lpt_cost;
+        Li.order = known ? sb.lpt_order : nullptr;
+        Li.order_next = (sb.lpt_age % 8u == 0u) ? sb.lpt_order : nullptr;
+        sb.lpt_age++;
+        sb.lpt_key = h;
+        return 0;
+    };
     auto launch_frames = [&](const RtLaunch &L0, const char **kerr) -> int {
         auto frame_launch = [&](size_t i, uint32_t parts, uint32_t part) {
             RtLaunch Li = L0;
@@ -551,24 +588,21 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             return Li;
         };
         if (!wavefront && !persistent && K == 1) {
-            // one kernel per frame, back to back on one stream: a single event pair around the whole sequence gives the
-            // average launch duration without putting a timing event between every two launches
-            RtProbe *pr = s->timing && s->sub[0].probe.used < s->sub[0].probe.capacity ? &s->sub[0].probe : nullptr;
-            if (pr && hipEventRecord(pr->events[2 * pr->used], st) != hipSuccess) return 1;
             for (size_t i = 0; i < n_frames; i++) {
-                int rc = rt_launch_render(s->d, frame_launch(i, 1, 0), nullptr, nullptr, st, kerr, nullptr);
+                RtLaunch Li = frame_launch(i, 1, 0);
+                if (attach_order(Li, 0, frames[i].u, st) != 0) return 1;
+                int rc = rt_launch_render(s->d, Li, nullptr, nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr);
                 if (rc != 0) return rc;
-            }
-            if (pr) {
-                if (hipEventRecord(pr->events[2 * pr->used + 1], st) != hipSuccess) return 1;
-                pr->launches[pr->used++] = (uint32_t)n_frames;
             }
             return 0;
         }
         if (K == 1) {
             for (size_t i = 0; i < n_frames; i++) {
                 const bool wf = wavefront && frames[i].u.max_recursion_limit >= 1;
-                int rc = rt_launch_render(s->d, frame_launch(i, 1, 0), wf ? &s->sub[0].ws : nullptr, (persistent && frames[i].u.max_recursion_limit >= 1) ? s->sub[0].pool : nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr);
+                const bool ps = persistent && frames[i].u.max_recursion_limit >= 1;
+                RtLaunch Li = frame_launch(i, 1, 0);
+                if (!wf && !ps && attach_order(Li, 0, frames[i].u, st) != 0) return 1;
+                int rc = rt_launch_render(s->d, Li, wf ? &s->sub[0].ws : nullptr, ps ? s->sub[0].pool : nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr);
                 if (rc != 0) return rc;
             }
             return 0;
@@ -578,7 +612,11 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             if (frame_launch(0, K, j).n_local_rows == 0) continue;
             if (hipStreamWaitEvent(s->sub[j].stream, s->fork_ev, 0) != hipSuccess) return 1;
             for (size_t i = 0; i < n_frames; i++) {
-                int rc = rt_launch_render(s->d, frame_launch(i, K, j), (wavefront && frames[i].u.max_recursion_limit >= 1) ? &s->sub[j].ws : nullptr, (persistent && frames[i].u.max_recursion_limit >= 1) ? s->sub[j].pool : nullptr, s->sub[j].stream, kerr, s->timing ? &s->sub[j].probe : nullptr);
+                const bool wf = wavefront && frames[i].u.max_recursion_limit >= 1;
+                const bool ps = persistent && frames[i].u.max_recursion_limit >= 1;
+                RtLaunch Li = frame_launch(i, K, j);
+                if (!wf && !ps && attach_order(Li, j, frames[i].u, s->sub[j].stream) != 0) return 1;
+                int rc = rt_launch_render(s->d, Li, wf ? &s->sub[j].ws : nullptr, ps ? s->sub[j].pool : nullptr, s->sub[j].stream, kerr, s->timing ? &s->sub[j].probe : nullptr);
                 if (rc != 0) return rc;
             }
             if (hipEventRecord(s->sub[j].done, s->sub[j].stream) != hipSuccess) return 1;
@@ -646,6 +684,7 @@ int rt_scene_destroy(rt_scene *s) {
         if (sb.done) (void)hipEventDestroy(sb.done);
         if (sb.block) (void)hipFree(sb.block);
         if (sb.pool) (void)hipFree(sb.pool);
+        if (sb.lpt_cost) (void)hipFree(sb.lpt_cost);
         if (sb.probe.events) { for (uint32_t i = 0; i < 2 * sb.probe.capacity; i++) if (sb.probe.events[i]) (void)hipEventDestroy(sb.probe.events[i]); delete[] sb.probe.events; delete[] sb.probe.launches; }
     }
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);

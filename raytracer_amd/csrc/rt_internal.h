@@ -56,6 +56,11 @@ struct RtLaunch {
     uint32_t compact_rows;
     uint32_t sub_parts, sub_part;   // this launch renders sub-frame sub_part of sub_parts of the caller's band (1, 0: all of it)
     uint32_t hot[4];                // tile rectangle (x0, y0, x1, y1 inclusive, 16x16 tiles of the local rows) where the octree projects to; x1 < x0: none
+    // Cost-ordered start of the one-lane-per-pixel kernel (all three null: index order).  order: permutation of the
+    // workgroup units to start in (most expensive first), cost: per-unit duration measured by this launch,
+    // order_next: where the launch leaves the permutation sorted by that cost for the next frame of the same view.
+    const uint32_t *order;
+    uint32_t *cost, *order_next;
     const float *ndc_x, *ndc_y;
     float *color, *depth, *hit_t;
     uint32_t *hit_kind, *hit_slot, *n_rays;
@@ -87,6 +92,7 @@ struct RtProbe {
 };
 
 // rt_kernels.hip
+size_t rt_render_units(uint32_t width, uint32_t n_local_rows);   // workgroups of the one-lane-per-pixel kernel
 size_t rt_pool_bytes();   // size of the persistent path kernel's tile-counter block
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
