@@ -36,6 +36,9 @@ DEVI float div_ieee(float a, float b) { return a / b; }
 DEVI float length3(f3 a) { return sqrt_ieee(dot3(a, a)); }
 DEVI f3 normalize3(f3 a) { float inv = rcp_ieee(sqrt_ieee(dot3(a, a))); return a * inv; }
 DEVI f3 rcp3(f3 a) { return F3(rcp_ieee(a.x), rcp_ieee(a.y), rcp_ieee(a.z)); }
+// Identity the optimiser cannot see through: a value derived from it is computed where it is used instead of being
+// hoisted out of the path loop and kept (or spilled) across the whole octree traversal.
+DEVI uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 DEVI uint32_t f2u(float f) { return __float_as_uint(f); }
 DEVI float u2f(uint32_t u) { return __uint_as_float(u); }
 DEVI bool is_inf(float x) { return __builtin_fabsf(x) == __builtin_inff(); }
@@ -570,8 +573,9 @@ DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const
     const f3 pd1 = F3(U.portal_direction_1[0], U.portal_direction_1[1], U.portal_direction_1[2]);
     const f3 pp2 = F3(U.portal_position_2[0], U.portal_position_2[1], U.portal_position_2[2]);
     const f3 pd2 = F3(U.portal_direction_2[0], U.portal_direction_2[1], U.portal_direction_2[2]);
-    const float p1 = ray_portal(r, pp1, pd1, portals[0], U.portal_width, U.portal_height, closest);
-    const float p2 = ray_portal(r, pp2, pd2, portals[1], U.portal_width, U.portal_height, closest);
+    const uint32_t first = opaque(0u);   // keeps the loads of the two bases next to their use
+    const float p1 = ray_portal(r, pp1, pd1, portals[first], U.portal_width, U.portal_height, closest);
+    const float p2 = ray_portal(r, pp2, pd2, portals[first + 1u], U.portal_width, U.portal_height, closest);
 
     Hit h;
     h.has_hit = false; h.position = F3(0, 0, 0); h.normal = F3(0, 0, 0); h.material_id = 0; h.portal_id = 0;
@@ -918,10 +922,11 @@ __global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDevice
             const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
             nrays++;
             if (i == 0) {   // the first segment's planes are stored at once instead of being carried through the path
-                if (L.depth) L.depth[p.pi] = first_hit_depth(L.u, h, ray);
-                if (L.hit_kind) L.hit_kind[p.pi] = tap.kind;
-                if (L.hit_slot) L.hit_slot[p.pi] = tap.slot;
-                if (L.hit_t) L.hit_t[p.pi] = tap.t;
+                const uint32_t pix = opaque((uint32_t)p.pi);   // (addresses formed here, not ahead of the loop)
+                if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
+                if (L.hit_kind) L.hit_kind[pix] = tap.kind;
+                if (L.hit_slot) L.hit_slot[pix] = tap.slot;
+                if (L.hit_t) L.hit_t[pix] = tap.t;
             }
             if (!h.has_hit) { color = color * sample_sky(S, ray.dir); break; }
             scatter(L.u, h, ray, color, seed);
