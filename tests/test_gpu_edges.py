@@ -1,0 +1,139 @@
+"""GPU edge cases against the oracle: ragged and tiny frames, zero path length, blending off, late accumulation indices,
+no skybox, degenerate geometry (flat root box, zero-area triangles), far-away and in-scene cameras, and node buffers that
+must be rejected instead of traversed."""
+import numpy as np
+import pytest
+
+from raytracer_amd import api, scenes
+from raytracer_amd.camera import Camera
+from raytracer_amd.params import Uniforms
+
+pytestmark = pytest.mark.gpu
+PIPELINES = ["megakernel", "wavefront", "persistent"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def same(o, g, what):
+    for k in ("kind", "slot", "nrays"):
+        assert np.array_equal(o[k], g[k]), (what, k)
+    for k in ("t", "depth", "rgba"):
+        assert np.array_equal(bits(o[k]), bits(g[k])), (what, k)
+
+
+@pytest.fixture(scope="module")
+def small_pair(test_sky):
+    from oracle import oracle
+    oc = scenes.small_test_scene()
+    sc = api.Scene.from_octree(oc)
+    sc.set_skybox(test_sky)
+    yield sc, oracle.OracleScene(oc.as_dict(), test_sky)
+    sc.close()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (17, 3), (333, 1), (1, 97), (130, 70)])
+def test_ragged_frame_sizes(small_pair, size):
+    sc, osc = small_pair
+    w, h = size
+    u = Uniforms.from_camera(Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=max(w / h, 0.05))).pack()
+    o = osc.render(u, w, h)
+    for pipe in PIPELINES:
+        sc.set_pipeline(pipe)
+        same(o, sc.render(u, w, h), (size, pipe))
+
+
+@pytest.mark.parametrize("kw", [dict(max_recursion_limit=0), dict(max_recursion_limit=1), dict(max_recursion_limit=12, blur_amount=0.05), dict(time=1.0e4)])
+def test_path_length_and_parameter_extremes(small_pair, kw):
+    sc, osc = small_pair
+    u = Uniforms.from_camera(Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=1.0), **kw).pack()
+    o = osc.render(u, 96, 96)
+    for pipe in PIPELINES:
+        sc.set_pipeline(pipe)
+        same(o, sc.render(u, 96, 96), (kw, pipe))
+
+
+def test_blend_off_and_late_accumulation_index(small_pair):
+    sc, osc = small_pair
+    u = Uniforms.from_camera(Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=1.0)).pack()
+    start = np.random.default_rng(3).random((64, 64, 4)).astype(np.float32)
+    for pipe in PIPELINES:
+        sc.set_pipeline(pipe)
+        for kw in (dict(blend=False, accum_index=7), dict(blend=True, accum_index=1000), dict(blend=True, accum_index=1)):
+            o = osc.render(u, 64, 64, rgba=start.copy(), **kw)
+            g = sc.render(u, 64, 64, color=start.copy(), **kw)
+            assert np.array_equal(bits(o["rgba"]), bits(g["rgba"])), (pipe, kw)
+
+
+def test_without_skybox_texture_returns_zero():
+    from oracle import oracle
+    oc = scenes.small_test_scene()
+    sc = api.Scene.from_octree(oc)
+    u = Uniforms.from_camera(Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=1.0)).pack()
+    same(oracle.OracleScene(oc.as_dict(), None).render(u, 64, 64), sc.render(u, 64, 64), "no sky")
+    sc.close()
+
+
+def test_degenerate_geometry(test_sky):
+    """A mesh in the plane y = 1.5 (flat root box: the strict tmin < tmax test never passes, frag:424) with zero-area
+    triangles among the rest, and the same mesh tilted so that it is hit."""
+    from oracle import oracle
+    rng = np.random.default_rng(11)
+    n = 40
+    xz = rng.uniform(-1.0, 1.0, (n, 3, 2)).astype(np.float32)
+    for flat in (True, False):
+        pos = np.zeros((n, 3, 3), np.float32)
+        pos[..., 0], pos[..., 2] = xz[..., 0], xz[..., 1]
+        pos[..., 1] = 1.5 if flat else 1.5 + 0.3 * xz[..., 0]
+        pos[5, 1] = pos[5, 0]                      # two equal vertices
+        pos[9, :] = pos[9, 0]                      # a point
+        mesh = api.Mesh(positions=pos.reshape(-1, 3), faces=np.arange(3 * n, dtype=np.uint32).reshape(-1, 3), material_id=4)
+        oc = api.Octree([mesh], 6, 4, 2, 3)
+        sc = api.Scene.from_octree(oc)
+        sc.set_skybox(test_sky)
+        osc = oracle.OracleScene(oc.as_dict(), test_sky)
+        u = Uniforms.from_camera(Camera(eye=(0.5, 3.0, 1.5), at=(0.0, 1.5, 0.0), aspect=1.0)).pack()
+        o = osc.render(u, 128, 128)
+        assert (o["kind"] == api.HIT_TRIANGLE).any() != flat
+        for pipe in PIPELINES:
+            sc.set_pipeline(pipe)
+            same(o, sc.render(u, 128, 128), (flat, pipe))
+        sc.close()
+
+
+@pytest.mark.parametrize("eye", [(1.0e4, 2.0e3, 5.0e3), (0.05, 1.6, 0.02), (0.0, -2.5, 0.0)])
+def test_camera_far_away_inside_the_mesh_and_below_the_ground(small_pair, eye):
+    sc, osc = small_pair
+    u = Uniforms.from_camera(Camera(eye=eye, at=(0.0, 1.5, 0.0), aspect=1.0, z_far=1.0e5)).pack()
+    o = osc.render(u, 96, 96)
+    for pipe in PIPELINES:
+        sc.set_pipeline(pipe)
+        same(o, sc.render(u, 96, 96), (eye, pipe))
+
+
+def test_malformed_node_buffers_are_rejected():
+    oc = scenes.small_test_scene()
+    d = oc.as_dict()
+    good = d["nodes"].copy()
+    assert (good[0] & 0xF) > 0
+
+    def create(nodes, **over):
+        dd = dict(d); dd["nodes"] = np.ascontiguousarray(nodes, np.uint32); dd.update(over)
+        return api.Scene.from_dict(dd)
+
+    create(good).close()
+    cases = {}
+    n = good.copy(); n[2] = len(good) + 5; cases["child pointer past the buffer"] = n
+    n = good.copy(); n[2] = 0; cases["child pointing back at the root (cycle)"] = n
+    n = good.copy(); n[0] = (n[0] & ~np.uint32(0xF)) | np.uint32(((n[0] & 0xF) % 8) + 1); cases["child count disagreeing with the mask"] = n
+    n = good.copy(); n[1] = np.uint32(len(d["tri_refs"])); n[0] |= np.uint32(3 << 16); cases["triangle range past the references"] = n
+    cases["truncated buffer"] = good[:1]
+    for what, nodes in cases.items():
+        with pytest.raises(api.RtError) as e:
+            create(nodes)
+        assert e.value.code == api.RT_ESCENE, what
+    bad_refs = d["tri_refs"].copy(); bad_refs.reshape(-1, 4)[0, 1] = len(d["vertices"]) + 7
+    with pytest.raises(api.RtError) as e:
+        create(good, tri_refs=bad_refs)
+    assert e.value.code == api.RT_ESCENE
