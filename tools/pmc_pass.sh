@@ -6,6 +6,6 @@ pipe=$1; limit=$2; shift 2
 i=0
 for pass in "$@"; do
   i=$((i+1))
-  timeout -s KILL 90 rocprofv3 --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${pipe}_$i -- python3 $GRAFT_REPO_ROOT/tools/time_render.py --scenes bunny --limits $limit --pipelines $pipe --subframes 1 --reps 3 > /dev/null 2>&1 || exit 1
+  timeout -s KILL 90 rocprofv3 --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${pipe}_$i -- python3 $GRAFT_REPO_ROOT/tools/time_render.py --scenes ${RT_PMC_SCENE:-bunny} --limits $limit --pipelines $pipe --subframes 1 --reps 3 > /dev/null 2>&1 || exit 1
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/pmc_${pipe}_$i
 done
