@@ -103,25 +103,57 @@ class FrameGatherer:
     """Gathers every frame's bands to rank `dst` while the next frame is already being rendered.
 
     submit(local) snapshots the rank's compact band buffer on the caller's current stream (a device-to-device copy;
-    the renderer keeps accumulating into `local`) and runs gather_frame on the snapshot on a side stream; the next
+    the renderer keeps accumulating into `local`) and, on a side stream, gathers the snapshots into one preallocated
+    [parts, rows, width, C] block on `dst` and re-interleaves that into the frame with a single strided copy; the next
     submit first waits until the previous gather has consumed the snapshot.  last() waits for the gather in flight and
-    returns the newest gathered frame on `dst` (None elsewhere).  On CPU tensors everything is synchronous."""
+    returns the newest frame on `dst` (None elsewhere).  Nothing is allocated per frame.  On CPU tensors everything is
+    synchronous."""
 
     def __init__(self, height: int, band_rows: int, dst: int = 0):
         self.height, self.band_rows, self.dst = height, band_rows, dst
         self.snap = None
+        self.stacked = None
         self.frame = None
         self.side = None
         self.done = None
+        self.submitted = False
 
-    def submit(self, local: torch.Tensor):
-        if not local.is_cuda:
-            self.frame = gather_frame(local, self.height, self.band_rows, self.dst)
-            return
-        if self.snap is None:
-            self.snap = torch.empty_like(local)
+    def _setup(self, local: torch.Tensor):
+        parts, rank = dist.get_world_size(), dist.get_rank()
+        pad = padded_row_count(self.height, self.band_rows, parts)
+        assert local.shape[0] == pad, (local.shape, pad)
+        self.snap = torch.empty_like(local)
+        if rank == self.dst:
+            self.stacked = torch.empty((parts,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            self.frame = torch.empty((pad * parts,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        if local.is_cuda:
             self.side = torch.cuda.Stream(device=local.device)
             self.done = torch.cuda.Event()
+
+    def _gather(self):
+        parts, rank = dist.get_world_size(), dist.get_rank()
+        staged = dist.get_backend() == "gloo" and self.snap.is_cuda      # gloo has no device gather
+        src = self.snap.cpu() if staged else self.snap
+        if rank == self.dst:
+            block = torch.empty_like(self.stacked, device="cpu") if staged else self.stacked
+            dist.gather(src, list(block.unbind(0)), dst=self.dst)
+            if staged:
+                self.stacked.copy_(block)
+            w_c = tuple(self.snap.shape[1:])
+            s_local = self.snap.shape[0] // self.band_rows
+            # [part, strip_local, band_rows, ...] -> [strip_local, part, band_rows, ...] = rows in frame order
+            self.frame.view((s_local, parts, self.band_rows) + w_c).copy_(self.stacked.view((parts, s_local, self.band_rows) + w_c).transpose(0, 1))
+        else:
+            dist.gather(src, None, dst=self.dst)
+
+    def submit(self, local: torch.Tensor):
+        if self.snap is None:
+            self._setup(local)
+        self.submitted = True
+        if not local.is_cuda:
+            self.snap.copy_(local)
+            self._gather()
+            return
         main = torch.cuda.current_stream(local.device)
         main.wait_event(self.done)          # the previous gather has read the snapshot (no-op the first time)
         self.snap.copy_(local)
@@ -129,10 +161,12 @@ class FrameGatherer:
         ready.record(main)
         self.side.wait_event(ready)
         with torch.cuda.stream(self.side):
-            self.frame = gather_frame(self.snap, self.height, self.band_rows, self.dst)
+            self._gather()
             self.done.record(self.side)
 
     def last(self):
         if self.side is not None:
             self.side.synchronize()
-        return self.frame
+        if not self.submitted or self.frame is None:
+            return None
+        return self.frame[:self.height]
