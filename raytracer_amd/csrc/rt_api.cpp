@@ -299,6 +299,15 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
             r.e2x = c[0] - a[0]; r.e2y = c[1] - a[1]; r.e2z = c[2] - a[2];
             r.pad[0] = r.pad[1] = r.pad[2] = 0;
         }
+        // A leaf has no child boxes to derive, so its box fields carry its first triangle record instead (nine floats
+        // either way): visiting a leaf with one triangle then takes one memory round trip, not two.
+        for (RtNodeRec &n : recs) {
+            if ((n.info & 0xFu) != 0u || (n.info >> 16) == 0u) continue;
+            const RtTriRec &r = tris[n.tri_start];
+            n.lo[0] = r.v1[0]; n.lo[1] = r.v1[1]; n.lo[2] = r.v1[2];
+            n.mid[0] = r.e1x; n.mid[1] = r.e1y; n.mid[2] = r.e1z;
+            n.hi[0] = r.e2x; n.hi[1] = r.e2y; n.hi[2] = r.e2z;
+        }
     }
 
     int ndev = 0;

@@ -11,7 +11,9 @@
 // (max+min)/2 is computed on the host with the same two IEEE operations).  Records are laid out breadth-first; a node
 // with children owns a block of eight consecutive records, the child in octant o being record first_child + o (the
 // slots of children that do not exist are never read), so a visit turns "octant passes the slab test" into a record
-// index without counting mask bits.  Built from the reference node words (Octree.cpp:44-75) by rt_scene_create.
+// index without counting mask bits.  A leaf (no children, so no child boxes to derive) carries the record of its first
+// triangle in the box fields: lo = v1, mid = e1, hi = e2.  Built from the reference node words (Octree.cpp:44-75) by
+// rt_scene_create.
 struct alignas(64) RtNodeRec {
     uint32_t info;        // tri_count << 16 | child_mask << 8 | child_count  (reference word 0)
     uint32_t tri_start;   // reference word 1

@@ -452,6 +452,15 @@ DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
     return n;
 }
 
+// The triangle record a leaf carries in place of its box (lo = v1, mid = e1, hi = e2).
+DEVI TriData inline_triangle(const NodeData &n) {
+    TriData d;
+    d.q0 = make_float4(n.lo.x, n.lo.y, n.lo.z, n.mid.x);
+    d.q1 = make_float4(n.mid.y, n.mid.z, n.hi.x, n.hi.y);
+    d.e2z = n.hi.z;
+    return d;
+}
+
 #ifndef TRI_BATCH
 #define TRI_BATCH 2u   // more in flight costs registers, and with them resident waves
 #endif
@@ -461,6 +470,8 @@ DEVI void visit_node(const RtDeviceScene &S, const Ray &r, STACK &st, float &clo
     const NodeData n = load_node(S, st.pop_node());
     if (COUNT) { cn.pops++; cn.tri_tests += n.tri_count; cn.box_tests += __popc(n.child_mask); }
     // triangle records are fetched TRI_BATCH at a time so that their memory latencies overlap; they are tested in order
+    // (the copy of a leaf's first triangle inside its node record is not used here: the extra branch per visit cost this
+    // kernel more than the saved round trip gave; walk_step uses it)
     for (uint32_t i0 = 0; i0 < n.tri_count; i0 += TRI_BATCH) {
         TriData td[TRI_BATCH];
 #pragma unroll
@@ -521,6 +532,11 @@ DEVI void walk_step(const RtDeviceScene &S, const Ray &r, STACK &st, Walk &w, fl
             w.node = load_node(S, st.pop_node());
             if (COUNT) { cn.pops++; cn.tri_tests += w.node.tri_count; cn.box_tests += __popc(w.node.child_mask); }
             w.tri_i = w.node.tri_start; w.tri_end = w.node.tri_start + w.node.tri_count;
+            if (w.node.child_mask == 0 && w.node.tri_count != 0) {   // a leaf's record holds its first triangle
+                const float t = ray_triangle(r, inline_triangle(w.node));
+                if (t >= 0.0f && t < closest) { closest = t; closest_tri = w.tri_i; tri_hit = true; }
+                w.tri_i++;
+            }
         }
     }
 }
