@@ -279,12 +279,12 @@ DEVI void sphere_accept(float b, float c, uint32_t i, float &closest, uint32_t &
 // The sphere records are read from a workgroup-shared LDS copy: loads the compiler can keep in flight ahead of the
 // arithmetic, whereas scalar loads from constant memory cannot be waited for individually.
 struct SphereLds { float4 tab[NUM_SPHERES]; SphereGrid grid; };
+// (no barrier of its own: stage_portals, which every kernel calls next, ends with the workgroup barrier for both)
 DEVI void stage_spheres(SphereLds *lds, const float4 *src) {
     for (uint32_t i = threadIdx.x; i < NUM_SPHERES; i += blockDim.x) lds->tab[i] = src[i];
     uint32_t *dst = reinterpret_cast<uint32_t *>(&lds->grid);
     const uint32_t *g = reinterpret_cast<const uint32_t *>(&c_sphere_grid);
     for (uint32_t i = threadIdx.x; i < sizeof(SphereGrid) / 4u; i += blockDim.x) dst[i] = g[i];
-    __syncthreads();
 }
 // Set of spheres that the ray can possibly be accepted by (a superset is always correct).
 struct SphereMask { uint32_t w[3]; };
@@ -588,9 +588,10 @@ DEVI PortalBasis portal_basis(f3 pn) {
     return b;
 }
 DEVI void stage_portals(PortalBasis *lds2, const rt_uniforms &U) {
-    if (threadIdx.x < 2) {
-        const float *d = threadIdx.x == 0 ? U.portal_direction_1 : U.portal_direction_2;
-        lds2[threadIdx.x] = portal_basis(F3(d[0], d[1], d[2]));
+    if (threadIdx.x >= blockDim.x - 2u) {   // the last two threads: the first ones are busy copying the sphere data
+        const uint32_t which = threadIdx.x - (blockDim.x - 2u);
+        const float *d = which == 0 ? U.portal_direction_1 : U.portal_direction_2;
+        lds2[which] = portal_basis(F3(d[0], d[1], d[2]));
     }
     __syncthreads();
 }
@@ -1085,6 +1086,7 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
     __shared__ uint32_t lds_base;
     __shared__ SphereLds lds_sph;
     stage_spheres(&lds_sph, D0 ? WS.prim : c_spheres);
+    __syncthreads();
     const uint32_t cur = depth & 1u;
     float4 *__restrict__ A = WS.pos_seed[cur];
     float4 *__restrict__ B = WS.dir_pix[cur];
