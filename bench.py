@@ -12,8 +12,9 @@ App::Render does (time advances by 1/60 s per frame).  One step = one frame.  Me
 FindIntersection call (path segment); rays are COUNTED by replaying the timed frames with the library's work counters on.
 
 N > 1: the frame is sharded by interleaved 16-row strips over the ranks (strong scaling), the scene is broadcast from
-rank 0 and every frame's bands are gathered to rank 0 with RCCL inside the timed region (the gather of frame k runs on a
-side stream while frame k+1 renders; the last gather is waited for before the clock stops).
+rank 0, every rank accumulates its own bands, and the accumulated frame is gathered to rank 0 with RCCL after every 16
+steps inside the timed region (on a side stream while rendering goes on; the last gather is waited for before the clock
+stops).  A 4K RGBA32F frame is 132.7 MB: gathered after every 0.1 ms step it would measure the xGMI links.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -73,7 +74,10 @@ def main():
     ap.add_argument("--scene", default="bunny", choices=["bunny", "synthetic_100k", "synthetic_1m"])
     ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront", "megakernel"])
     ap.add_argument("--subframes", type=int, default=None)
-    ap.add_argument("--per-frame-calls", action="store_true", help="N = 1: one rt_render per step instead of one rt_render_sequence over the K steps")
+    ap.add_argument("--per-frame-calls", action="store_true", help="one rt_render per step instead of rt_render_sequence calls")
+    ap.add_argument("--present-every", type=int, default=16,
+                    help="N > 1: the accumulated frame is gathered to rank 0 after every this many steps (a 4K RGBA32F frame is 132.7 MB: "
+                         "gathering it after every 0.1 ms step would measure the xGMI links, not the renderer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,21 +156,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # One step = one frame.  On one GPU the K frames are the library's progressive-accumulation sequence (one
-    # rt_render_sequence call: consecutive frames of a still camera pipeline inside the library); on several GPUs
-    # every frame's bands are gathered to rank 0, so frames are issued one by one.
-    sequence = world == 1 and not args.per_frame_calls
+    # One step = one frame.  Frames are issued as the library's progressive-accumulation sequences (rt_render_sequence).
+    # On several GPUs every rank accumulates its own bands; the accumulated frame is presented -- its bands gathered to
+    # rank 0 on a side stream while rendering goes on -- after every `present_every` steps and after the last one.
+    sequence = not args.per_frame_calls
+    present_every = max(1, args.present_every)
 
     def run_steps(frames):
-        if sequence:
-            sc.render_sequence_raw(frames, target_of())
-        else:
-            for fr in frames:
-                sc.render_raw(fr, target_of())
-                if world > 1:
-                    gatherer.submit(color)
+        chunk = len(frames) if world == 1 else present_every
+        for first in range(0, len(frames), max(chunk, 1)):
+            part = frames[first:first + chunk]
+            if sequence:
+                sc.render_sequence_raw(part, target_of())
+            else:
+                for fr in part:
+                    sc.render_raw(fr, target_of())
             if world > 1:
-                gatherer.last()
+                gatherer.submit(color)
+        if world > 1:
+            gatherer.last()
 
     # the per-frame inputs (camera matrices, time) are prepared before the clock starts: they are the caller's data
     warm_frames = [frame_of(k, k + 1) for k in range(args.warmup)]
@@ -221,13 +229,13 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": ("REHEARSAL on one GPU, not a measurement; " if rehearse else "") + "synthetic camera/skybox; bundled bunny mesh (default scene's dragon is absent from the reference checkout)",
         "config": {"workload": f"{args.scene} default-style scene {W}x{H}, max_recursion_limit={args.max_recursion_limit} (primary + one secondary segment), 1 spp/frame, progressive accumulation",
                    "width": W, "height": H, "max_recursion_limit": args.max_recursion_limit, "band_rows": BAND_ROWS,
-                   "parallelism": f"interleaved row bands x{world}" + (" + RCCL gather per frame" if world > 1 else "")},
+                   "parallelism": f"interleaved row bands x{world}" + (f" + RCCL gather of the accumulated frame every {max(1, args.present_every)} steps" if world > 1 else "")},
         "rays_per_frame": rays / args.steps, "rays_per_pixel": rays / args.steps / (W * H),
         "work_per_frame": {k: v / args.steps for k, v in tot.items()},
         "scene_build_s": round(t_build, 3),
     }
     out["config"]["pipeline"] = pipeline + (" (selected by the library: measured ms/frame %s)" % {k: (round(v, 3) if v is not None else None) for k, v in pipeline_ms.items()} if args.pipeline == "auto" else "")
-    out["config"]["issue"] = "rt_render_sequence over the K steps" if sequence else "one rt_render per step"
+    out["config"]["issue"] = ("rt_render_sequence over the K steps" if world == 1 else f"rt_render_sequence per {present_every} steps") if sequence else "one rt_render per step"
     # ---- roofline of the dominant kernel, this rank's launches --------------------------------------------------
     kernel = {"wavefront": "traverse_kernel", "megakernel": "render_kernel", "persistent": "path_kernel"}[pipeline]
     k_ms = k_total_ms / max(k_launches, 1)
