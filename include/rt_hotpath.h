@@ -168,6 +168,11 @@ int rt_scene_pipeline_state(rt_scene *scene, int *selected, double ms_per_frame[
  * where consecutive frames of a sub-frame follow each other without a join).  A sub-frame is never smaller than 2^19
  * pixels.  Results do not depend on n. */
 int rt_scene_set_subframes(rt_scene *scene, int n);
+/* One-kernel-per-frame pipeline inside rt_render_sequence: when a launch covers only a small part of a 4K frame (one
+ * rank's bands, a small window), up to max_frames (2..8) consecutive frames are traced by one launch -- their samples
+ * are independent -- and blended into the target in frame order by a second small kernel; the pixels are the same.
+ * 0 (default): chosen from the size of the launch; 1: never. */
+int rt_scene_set_sequence_batch(rt_scene *scene, int max_frames);
 int rt_scene_destroy(rt_scene *scene);
 
 /* Host-side scene build: mirrors of the reference's Mesh and Octree classes --------------------------------- */

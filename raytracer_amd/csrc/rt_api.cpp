@@ -74,6 +74,9 @@ struct rt_scene {
     } sub[RT_MAX_SUBFRAMES];
     bool timing = false;
     hipEvent_t fork_ev = nullptr;
+    void *stage = nullptr;      // sample staging of batched sequence launches (RtBatch)
+    size_t stage_elems = 0;
+    int max_batch = 0;          // 0: automatic; 1: never batch
     // RT_PIPELINE_AUTO: the three pipelines give identical pixels, so the scene measures them on its own frames (event
     // pairs around a call's launches, read back without blocking at a later call) and uses the fastest for the workload
     // at hand; the others are measured again now and then.
@@ -375,6 +378,13 @@ int rt_scene_pipeline_state(rt_scene *s, int *selected, double ms_per_frame[3]) 
     return RT_OK;
 }
 
+int rt_scene_set_sequence_batch(rt_scene *s, int max_frames) {
+    if (!s) return fail(RT_EINVAL, "scene is null");
+    if (max_frames < 0 || max_frames > RT_MAX_BATCH) return fail(RT_EINVAL, "batch must be in [0,%d]", RT_MAX_BATCH);
+    s->max_batch = max_frames;
+    return RT_OK;
+}
+
 int rt_scene_set_subframes(rt_scene *s, int n) {
     if (!s) return fail(RT_EINVAL, "scene is null");
     if (n < 1 || n > RT_MAX_SUBFRAMES) return fail(RT_EINVAL, "subframes must be in [1,%d]", RT_MAX_SUBFRAMES);
@@ -597,11 +607,33 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             return Li;
         };
         if (!wavefront && !persistent && K == 1) {
-            for (size_t i = 0; i < n_frames; i++) {
+            // A launch that covers only a small part of the frame (one of several ranks' bands, a small window) cannot
+            // keep the machine busy and still lasts as long as its longest path, so consecutive frames of a sequence are
+            // traced together: `batch` frames per launch, enough for about a 4K frame's worth of pixels (see RtBatch).
+            const size_t px = (size_t)f->width * L0.n_local_rows;
+            size_t batch = px ? std::min<size_t>(RT_MAX_BATCH, ((size_t)1 << 23) / px) : 1;
+            if (s->max_batch > 0) batch = std::min<size_t>(batch, (size_t)s->max_batch);
+            for (size_t i = 0; i < n_frames;) {
+                const size_t nb = std::min(batch, n_frames - i);
                 RtLaunch Li = frame_launch(i, 1, 0);
                 if (attach_order(Li, 0, frames[i].u, st) != 0) return 1;
-                int rc = rt_launch_render(s->d, Li, nullptr, nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr);
+                if (nb < 2) {
+                    int rc = rt_launch_render(s->d, Li, nullptr, nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr);
+                    if (rc != 0) return rc;
+                    i++;
+                    continue;
+                }
+                if (s->stage_elems < nb * px) {
+                    if (s->stage) { if (hipDeviceSynchronize() != hipSuccess) return 1; (void)hipFree(s->stage); s->stage = nullptr; s->stage_elems = 0; }
+                    if (hipMalloc(&s->stage, batch * px * 16) != hipSuccess) return 1;
+                    s->stage_elems = batch * px;
+                }
+                RtBatch B{};
+                for (size_t k = 0; k < nb; k++) { B.u[k] = frames[i + k].u; B.accum_index[k] = frames[i + k].accum_index; B.blend[k] = frames[i + k].blend ? 1u : 0u; }
+                B.n = (uint32_t)nb; B.stage_stride = (uint32_t)px; B.stage = (float4 *)s->stage;
+                int rc = rt_launch_render(s->d, Li, nullptr, nullptr, st, kerr, s->timing ? &s->sub[0].probe : nullptr, &B);
                 if (rc != 0) return rc;
+                i += nb;
             }
             return 0;
         }
@@ -697,6 +729,7 @@ int rt_scene_destroy(rt_scene *s) {
         if (sb.probe.events) { for (uint32_t i = 0; i < 2 * sb.probe.capacity; i++) if (sb.probe.events[i]) (void)hipEventDestroy(sb.probe.events[i]); delete[] sb.probe.events; delete[] sb.probe.launches; }
     }
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+    if (s->stage) (void)hipFree(s->stage);
     if (s->tuner.a) (void)hipEventDestroy(s->tuner.a);
     if (s->tuner.b) (void)hipEventDestroy(s->tuner.b);
     delete s;

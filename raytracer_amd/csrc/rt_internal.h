@@ -84,6 +84,20 @@ struct RtWorkspace {
     float4 *prim;          // per-frame (oc.xyz, c) of the 84 spheres for rays starting at the camera
 };
 
+// Several consecutive frames of a sequence traced by ONE launch of the one-lane-per-pixel kernel.  Samples of different
+// frames are independent; only the blend into the target is ordered.  The launch therefore covers n frames x the
+// launch's pixels, writes every sample's tonemapped colour to stage[frame][local pixel], and a second small kernel blends
+// the samples of each pixel in frame order.  With that a launch keeps the machine busy even when its share of the frame
+// is small (one of 8 ranks' bands), instead of ending on the serial chain of its single longest path n times over.
+#define RT_MAX_BATCH 8
+struct RtBatch {
+    rt_uniforms u[RT_MAX_BATCH];
+    uint32_t accum_index[RT_MAX_BATCH], blend[RT_MAX_BATCH];
+    uint32_t n;                 // frames in this launch (2..RT_MAX_BATCH)
+    uint32_t stage_stride;      // float4 elements per frame in `stage` (= width x n_local_rows)
+    float4 *stage;
+};
+
 // Optional timing of the dominant kernel (the traversal kernel of the wavefront pipeline, the single kernel of the
 // other): pairs of HIP events recorded on the launch stream directly before and after each such launch.
 struct RtProbe {
@@ -100,4 +114,5 @@ size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
 // pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:
 // one-lane-per-pixel kernel; otherwise the per-depth wavefront pipeline.
-int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, uint32_t *pool, void *stream, const char **err, RtProbe *probe = nullptr);
+int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, uint32_t *pool, void *stream, const char **err, RtProbe *probe = nullptr,
+                     const RtBatch *batch = nullptr);   // batch: one-lane-per-pixel pipeline only; launch.u / accum_index / blend are then ignored

@@ -830,17 +830,20 @@ DEVI f3 tonemap(f3 color) {
 
 // Colour attachment write with the blend state of App.cpp:49,104: dst = src*(1/n) + dst*(1 - 1/n) on all four
 // channels (src alpha = 0), or a plain store when blending is off.
-DEVI void write_pixel(const RtLaunch &L, size_t pi, f3 c) {
-    float4 *dstp = reinterpret_cast<float4 *>(L.color) + pi;
+DEVI float4 blend_sample(float4 dst, f3 c, uint32_t accum_index, uint32_t blend) {
     float4 out;
-    if (L.blend) {
-        const float a = rcp_ieee((float)L.accum_index), ia = 1.0f - a;
-        const float4 dst = *dstp;
+    if (blend) {
+        const float a = rcp_ieee((float)accum_index), ia = 1.0f - a;
         out.x = c.x * a + dst.x * ia; out.y = c.y * a + dst.y * ia; out.z = c.z * a + dst.z * ia; out.w = 0.0f * a + dst.w * ia;
     } else {
         out.x = c.x; out.y = c.y; out.z = c.z; out.w = 0.0f;
     }
-    *dstp = out;
+    return out;
+}
+DEVI void write_pixel(const RtLaunch &L, size_t pi, f3 c) {
+    float4 *dstp = reinterpret_cast<float4 *>(L.color) + pi;
+    const float4 dst = L.blend ? *dstp : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    *dstp = blend_sample(dst, c, L.accum_index, L.blend);
 }
 
 // Pixel addressing shared by both pipelines: one wave per 8x8 pixel tile, 4 waves (a 16x16 tile) per workgroup;
@@ -935,13 +938,18 @@ DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
 #ifndef RENDER_BLOCK
 #define RENDER_BLOCK 128   // threads per workgroup: a workgroup keeps its LDS until its slowest wave ends, so small ones free the CU sooner
 #endif
-template <int LEVELS, bool COUNT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDeviceScene S, RtLaunch L) {
+// BATCH: the launch traces B.n consecutive frames (see RtBatch); workgroup `blockIdx.x` then renders frame blockIdx.x % n
+// of unit blockIdx.x / n, so that the expensive units of all frames still start first.
+template <int LEVELS, bool COUNT, int BLOCK, bool BATCH>
+DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *B) {
     __shared__ uint32_t lds_stack[LEVELS * BLOCK];
     __shared__ SphereLds lds_sph;
-    __shared__ PortalBasis lds_portals[2];
+    __shared__ PortalBasis lds_portals_all[2];
+    const uint32_t frame = BATCH ? blockIdx.x % B->n : 0u;
+    const rt_uniforms &U = BATCH ? B->u[frame] : L.u;
     stage_spheres(&lds_sph, c_spheres);
-    stage_portals(lds_portals, L.u);
+    stage_portals(lds_portals_all, U);
+    const PortalBasis *lds_portals = lds_portals_all;
     LevelStackT<BLOCK> st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
@@ -949,7 +957,8 @@ __global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDevice
     // paths are under way early and the kernel does not end on them (measured: 1.04 -> 0.95 ms per 4K frame)
     // With a cost order from the previous frame of the same view (L.order) the most expensive units start first.
     const unsigned long long t_start = L.cost ? wall_clock64() : 0ull;
-    const uint32_t unit = L.order ? L.order[blockIdx.x] : blockIdx.x;
+    const uint32_t slot = BATCH ? blockIdx.x / B->n : blockIdx.x;
+    const uint32_t unit = L.order ? L.order[slot] : slot;
     uint32_t tile_x, tile_y;
     path_tile(L, unit / (256u / BLOCK), tile_x, tile_y);
     const PixelId p = pixel_of_tile(L, tile_x, tile_y, (unit % (256u / BLOCK)) * BLOCK + threadIdx.x);
@@ -960,18 +969,18 @@ __global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDevice
         Ray ray;
         Seed seed;
         seed.k = 0;
-        ray.pos = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]);
-        generate_ray(L.u, nx, ny, ray.dir, seed.base);
+        ray.pos = F3(U.camera_position[0], U.camera_position[1], U.camera_position[2]);
+        generate_ray(U, nx, ny, ray.dir, seed.base);
         ray.inv = rcp3(ray.dir);
         f3 color = F3(1.0f, 1.0f, 1.0f);
         uint32_t nrays = 0;
-        if (L.u.max_recursion_limit == 0) {   // no segment at all: the planes of the first segment keep their initial values
+        if (U.max_recursion_limit == 0 && (!BATCH || frame + 1u == B->n)) {   // no segment at all: the planes of the first segment keep their initial values
             if (L.depth) L.depth[p.pi] = 1.0f;
             if (L.hit_kind) L.hit_kind[p.pi] = RT_HIT_MISS;
             if (L.hit_slot) L.hit_slot[p.pi] = 0;
             if (L.hit_t) L.hit_t[p.pi] = __builtin_inff();
         }
-        for (uint32_t i = 0; i < L.u.max_recursion_limit; i++) {
+        for (uint32_t i = 0; i < U.max_recursion_limit; i++) {
             float closest = __builtin_inff();
             uint32_t closest_i = 0, closest_tri = 0;
             bool tri_hit = false;
@@ -984,24 +993,53 @@ __global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDevice
                 while (!st.empty()) visit_node<COUNT>(S, ray, st, closest, closest_tri, tri_hit, cn);
             }
             PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
-            const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
+            const Hit h = finish_intersection<COUNT>(S, U, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
             nrays++;
             if (i == 0) {   // the first segment's planes are stored at once instead of being carried through the path
                 const uint32_t pix = opaque((uint32_t)p.pi);   // (addresses formed here, not ahead of the loop)
-                if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
+                if (BATCH && frame + 1u != B->n) { /* the planes keep the last frame's values */ } else {
+                if (L.depth) L.depth[pix] = first_hit_depth(U, h, ray);
                 if (L.hit_kind) L.hit_kind[pix] = tap.kind;
                 if (L.hit_slot) L.hit_slot[pix] = tap.slot;
                 if (L.hit_t) L.hit_t[pix] = tap.t;
+                }
             }
             if (!h.has_hit) { color = color * sample_sky(S, ray.dir); break; }
-            scatter(L.u, h, ray, color, seed);
+            scatter(U, h, ray, color, seed);
             ray.inv = rcp3(ray.dir);
         }
-        write_pixel(L, p.pi, tonemap(color));
-        if (L.n_rays) L.n_rays[p.pi] = nrays;
+        const f3 out = tonemap(color);
+        if (BATCH) B->stage[(size_t)frame * B->stage_stride + (size_t)p.lr * L.width + p.x] = make_float4(out.x, out.y, out.z, 0.0f);
+        else write_pixel(L, p.pi, out);
+        if (L.n_rays && (!BATCH || frame + 1u == B->n)) L.n_rays[p.pi] = nrays;
     }
     if (L.cost && (threadIdx.x & 63u) == 0) atomicMax(&L.cost[unit], (uint32_t)min(wall_clock64() - t_start, 0xFFFFFFFFull) + 1u);
     if (COUNT && L.counters) flush_counters(L.counters, cn);
+}
+
+template <int LEVELS, bool COUNT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDeviceScene S, RtLaunch L) {
+    render_body<LEVELS, COUNT, BLOCK, false>(S, L, nullptr);
+}
+template <int LEVELS, bool COUNT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_batch_kernel(RtDeviceScene S, RtLaunch L, RtBatch B) {
+    render_body<LEVELS, COUNT, BLOCK, true>(S, L, &B);
+}
+// Blends the staged samples of a batch into the target, frame after frame per pixel (App.cpp:49,102-105).
+__global__ __launch_bounds__(256) void blend_batch_kernel(RtLaunch L, RtBatch B) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= L.width * L.n_local_rows) return;
+    const uint32_t x = i % L.width, lr = i / L.width;
+    const uint32_t y = ((lr / L.band_rows) * L.band_parts + L.band_part) * L.band_rows + (lr % L.band_rows);
+    if (y >= L.height) return;
+    const uint32_t part_lr = ((lr / L.band_rows) * L.sub_parts + L.sub_part) * L.band_rows + (lr % L.band_rows);
+    float4 *dstp = reinterpret_cast<float4 *>(L.color) + (L.compact_rows ? (size_t)part_lr * L.width + x : (size_t)y * L.width + x);
+    float4 dst = *dstp;
+    for (uint32_t f = 0; f < B.n; f++) {
+        const float4 c = B.stage[(size_t)f * B.stage_stride + i];
+        dst = blend_sample(dst, F3(c.x, c.y, c.z), B.accum_index[f], B.blend[f]);
+    }
+    *dstp = dst;
 }
 
 // Sorts the workgroup units by measured cost, most expensive first, into `order` (a counting sort over 128 logarithmic
@@ -1461,8 +1499,15 @@ void launch_path(const RtDeviceScene &S, const RtLaunch &L, uint32_t *pool, uint
 }
 
 template <int LEVELS>
-int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid) {
+int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid, const RtBatch *batch) {
     grid.x *= 256u / RENDER_BLOCK;
+    if (batch) {
+        grid.x *= batch->n;
+        if (L.counters) hipLaunchKernelGGL((render_batch_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
+        else hipLaunchKernelGGL((render_batch_kernel<LEVELS, false, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
+        hipLaunchKernelGGL(blend_batch_kernel, dim3((L.width * L.n_local_rows + 255u) / 256u), dim3(256), 0, st, L, *batch);
+        return (int)hipGetLastError();
+    }
     if (L.counters) hipLaunchKernelGGL((render_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L);
     else hipLaunchKernelGGL((render_kernel<LEVELS, false, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L);
     return (int)hipGetLastError();
@@ -1490,7 +1535,7 @@ size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows) {
 }
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows) { return rt_workspace_ranges(width, n_local_rows) * RANGE; }
 
-int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe) {
+int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe, const RtBatch *batch) {
     const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
     if (tiles_x == 0 || tiles_y == 0) return 0;
     const uint32_t n_tiles = tiles_x * tiles_y;
@@ -1520,9 +1565,9 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
     } else if (!WS) {
         const dim3 grid(n_tiles);
         mark(0);
-        if (need <= 12) rc = launch_megakernel<12>(S, L, st, grid);
-        else if (need <= 20) rc = launch_megakernel<20>(S, L, st, grid);
-        else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid);
+        if (need <= 12) rc = launch_megakernel<12>(S, L, st, grid, batch);
+        else if (need <= 20) rc = launch_megakernel<20>(S, L, st, grid, batch);
+        else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid, batch);
         mark(1);
         if (L.cost && L.order_next) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, L.cost, L.order_next, n_tiles * (256u / RENDER_BLOCK));
         if (timed) probe->launches[probe->used++] = 1;

@@ -252,3 +252,38 @@ def test_auto_pipeline_selection_is_invisible(bunny_octree, test_sky):
     assert all(v is not None and v > 0 for v in ms.values()), ms
     assert selected == min(ms, key=ms.get)
     sc.close()
+
+
+def test_batched_sequence_of_small_frames(bunny_octree, test_sky):
+    """Small launches inside rt_render_sequence are traced several frames at a time (samples staged, then blended in
+    frame order): colour, depth and the debug planes equal frame-by-frame rendering, also on a band part in compact
+    addressing, with a frame that stores instead of blending and one with no path segments in the middle."""
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(test_sky)
+    sc.set_pipeline("megakernel")
+    w, h, n = 640, 360, 11
+    us = [Uniforms.from_camera(Camera(aspect=w / h), time=k / 60.0, max_recursion_limit=(0 if k == 6 else 3)).pack() for k in range(n)]
+    blends = [k != 4 for k in range(n)]
+    for band, compact in (((16, 1, 0), False), ((16, 3, 1), True), ((16, 2, 0), False)):
+        fr0 = api.make_frame(us[0], w, h, band=band, compact=compact)
+        rows = api.band_row_count(fr0) if compact else h
+        def fresh():
+            return dict(color=np.full((rows, w, 4), 0.25, np.float32), depth=np.zeros((rows, w), np.float32), kind=np.zeros((rows, w), np.uint32),
+                        slot=np.zeros((rows, w), np.uint32), t=np.zeros((rows, w), np.float32), nrays=np.zeros((rows, w), np.uint32))
+        def target(b):
+            tg = api.rt_target()
+            tg.memory, tg.sync = api.RT_MEM_HOST, 1
+            tg.color, tg.depth, tg.hit_kind, tg.hit_slot, tg.hit_t, tg.n_rays = (b[k].ctypes.data for k in ("color", "depth", "kind", "slot", "t", "nrays"))
+            return tg
+        frames = [api.make_frame(us[k], w, h, accum_index=k + 1, blend=blends[k], band=band, compact=compact) for k in range(n)]
+        ref = fresh()
+        sc.set_sequence_batch(1)
+        for fr in frames:
+            sc.render_raw(fr, target(ref))
+        for batch in (0, 2, 8):
+            sc.set_sequence_batch(batch)
+            got = fresh()
+            sc.render_sequence_raw(frames, target(got))
+            for k in ref:
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (band, batch, k)
+    sc.close()
