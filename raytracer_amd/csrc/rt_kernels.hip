@@ -938,18 +938,35 @@ DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
 #ifndef RENDER_BLOCK
 #define RENDER_BLOCK 128   // threads per workgroup: a workgroup keeps its LDS until its slowest wave ends, so small ones free the CU sooner
 #endif
-// BATCH: the launch traces B.n consecutive frames (see RtBatch); workgroup `blockIdx.x` then renders frame blockIdx.x % n
-// of unit blockIdx.x / n, so that the expensive units of all frames still start first.
+// BATCH: the launch traces B->n consecutive frames (see RtBatch), the expensive units of all frames still first.
 template <int LEVELS, bool COUNT, int BLOCK, bool BATCH>
 DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *B) {
     __shared__ uint32_t lds_stack[LEVELS * BLOCK];
     __shared__ SphereLds lds_sph;
-    __shared__ PortalBasis lds_portals_all[2];
-    const uint32_t frame = BATCH ? blockIdx.x % B->n : 0u;
+    constexpr uint32_t WAVES = BLOCK / 64u;
+    __shared__ PortalBasis lds_portals_all[BATCH ? 2u * WAVES : 2u];
+    // BATCH: the waves of a workgroup render the SAME 8x8 pixels for different frames of the batch.  Their primary rays
+    // differ only by the sub-pixel jitter, so they walk the same nodes and triangles at the same time and share the
+    // CU's vector cache.  Workgroup b: frames (b % groups) * WAVES + wave, 8x8 tile b / groups of the cost-ordered list.
+    const uint32_t groups = BATCH ? (B->n + WAVES - 1u) / WAVES : 1u;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t frame_raw = BATCH ? (blockIdx.x % groups) * WAVES + wave : 0u;
+    const bool frame_ok = !BATCH || frame_raw < B->n;
+    const uint32_t frame = BATCH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)min(frame_raw, B->n - 1u)) : 0u;
     const rt_uniforms &U = BATCH ? B->u[frame] : L.u;
     stage_spheres(&lds_sph, c_spheres);
-    stage_portals(lds_portals_all, U);
-    const PortalBasis *lds_portals = lds_portals_all;
+    if (BATCH) {
+        if (threadIdx.x >= BLOCK - 2u * WAVES) {
+            const uint32_t which = threadIdx.x - (BLOCK - 2u * WAVES);
+            const uint32_t f = min((blockIdx.x % groups) * WAVES + which / 2u, B->n - 1u);
+            const float *d = (which & 1u) == 0 ? B->u[f].portal_direction_1 : B->u[f].portal_direction_2;
+            lds_portals_all[which] = portal_basis(F3(d[0], d[1], d[2]));
+        }
+        __syncthreads();
+    } else {
+        stage_portals(lds_portals_all, U);
+    }
+    const PortalBasis *lds_portals = lds_portals_all + (BATCH ? 2u * wave : 0u);
     LevelStackT<BLOCK> st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
@@ -957,11 +974,13 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
     // paths are under way early and the kernel does not end on them (measured: 1.04 -> 0.95 ms per 4K frame)
     // With a cost order from the previous frame of the same view (L.order) the most expensive units start first.
     const unsigned long long t_start = L.cost ? wall_clock64() : 0ull;
-    const uint32_t slot = BATCH ? blockIdx.x / B->n : blockIdx.x;
+    const uint32_t q = BATCH ? blockIdx.x / groups : 0u;                       // BATCH: 8x8 tile index in the ordered list
+    const uint32_t slot = BATCH ? q / WAVES : blockIdx.x;
     const uint32_t unit = L.order ? L.order[slot] : slot;
     uint32_t tile_x, tile_y;
     path_tile(L, unit / (256u / BLOCK), tile_x, tile_y);
-    const PixelId p = pixel_of_tile(L, tile_x, tile_y, (unit % (256u / BLOCK)) * BLOCK + threadIdx.x);
+    PixelId p = pixel_of_tile(L, tile_x, tile_y, (unit % (256u / BLOCK)) * BLOCK + (BATCH ? (q % WAVES) * 64u + lane : threadIdx.x));
+    p.active = p.active && frame_ok;
     Counters cn = {0, 0, 0, 0, 0, 0};
     if (p.active) {
         float nx, ny;
@@ -1502,7 +1521,8 @@ template <int LEVELS>
 int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid, const RtBatch *batch) {
     grid.x *= 256u / RENDER_BLOCK;
     if (batch) {
-        grid.x *= batch->n;
+        constexpr uint32_t WAVES = RENDER_BLOCK / 64u;
+        grid.x *= WAVES * ((batch->n + WAVES - 1u) / WAVES);   // one workgroup per 8x8 tile and group of WAVES frames
         if (L.counters) hipLaunchKernelGGL((render_batch_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
         else hipLaunchKernelGGL((render_batch_kernel<LEVELS, false, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
         return (int)hipGetLastError();
