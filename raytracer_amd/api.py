@@ -79,6 +79,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RtError(RT_ENODEVICE, f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` (there is no CPU fallback)")
+        # PyTorch-ROCm wheels carry their own copy of the HIP runtime under another file name.  Loaded after this library's
+        # it becomes a SECOND runtime in the process and finds no GPU; loaded first, the dynamic loader gives this library
+        # the same copy (equal soname).  So a process that can use torch at all gets it loaded here, before the library.
+        import importlib.util
+        import sys
+        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.rt_last_error.restype = C.c_char_p
         L.rt_device_count.argtypes = [C.POINTER(C.c_int)]

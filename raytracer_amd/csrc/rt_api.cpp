@@ -87,6 +87,9 @@ struct rt_scene {
         uint32_t calls = 0;
         int pending = -1;                  // pipeline of the measurement in flight
         uint32_t pending_frames = 0;
+        bool look_again = false;            // the periodic second look at the slower pipelines is due
+        bool in_split = false;              // inside a long sequence that is issued as probe part + rest
+        bool no_explore = false;            // this call must use the best known pipeline
         hipEvent_t a = nullptr, b = nullptr;
     } tuner;
 };
@@ -477,11 +480,15 @@ static int tuner_choose(rt_scene *s, uint64_t key, bool *measure) {
     int best = -1;
     for (int p = 0; p < 3; p++) if (t.ms[p] >= 0.0 && (best < 0 || t.ms[p] < t.ms[best])) best = p;
     int choice = best >= 0 ? best : RT_PIPELINE_MEGAKERNEL;
+    if (t.calls % 64u == 0u) t.look_again = true;
     if (t.pending < 0) {
         *measure = true;
-        for (int p = 0; p < 3; p++) if (t.ms[p] < 0.0) { choice = p; break; }                 // something still unknown: try it
-        if (best >= 0 && t.ms[0] >= 0.0 && t.ms[1] >= 0.0 && t.ms[2] >= 0.0 && t.calls % 64u == 0u)
-            choice = (best + 1 + (int)((t.calls / 64u) % 2u)) % 3;                            // look at the others again now and then
+        if (t.no_explore) return choice;
+        for (int p = 0; p < 3; p++) if (t.ms[p] < 0.0) return p;                              // something still unknown: try it
+        if (t.look_again) {                                                                   // look at the others again now and then
+            t.look_again = false;
+            choice = (best + 1 + (int)((t.calls / 64u) % 2u)) % 3;
+        }
     }
     return choice;
 }
@@ -508,6 +515,21 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         if (frames[i].accum_index == 0) return fail(RT_EINVAL, "accum_index must be >= 1");
         if (!same_geometry(frames[i], *f)) return fail(RT_EINVAL, "frame %zu of the sequence differs from frame 0 in size, band, ndc table or stream", i);
         if (frames[i].u.max_recursion_limit < min_limit) min_limit = frames[i].u.max_recursion_limit;
+    }
+    // Trying a pipeline other than the best known one must not cost a whole long sequence (64 samples of a still camera
+    // at 8K are 0.2 s): a long sequence is issued as a short probe part, which the selection may use to try a pipeline,
+    // and the rest, which always runs on the best one known.
+    const size_t probe_frames = (size_t)f->width * f->height >= ((size_t)1 << 23) ? 4 : 8;
+    if (s->pipeline == RT_PIPELINE_AUTO && !s->tuner.in_split && !s->counting && t->memory == RT_MEM_DEVICE && n_frames > 2 * probe_frames) {
+        rt_target head = *t;
+        head.sync = 0;
+        s->tuner.in_split = true;
+        int rc = render_frames(s, frames, probe_frames, &head);
+        s->tuner.no_explore = true;
+        if (rc == RT_OK) rc = render_frames(s, frames + probe_frames, n_frames - probe_frames, t);
+        s->tuner.no_explore = false;
+        s->tuner.in_split = false;
+        return rc;
     }
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);

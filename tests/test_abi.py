@@ -55,3 +55,19 @@ def test_no_cpu_fallback():
     with pytest.raises(api.RtError) as e:
         api.Scene(np.zeros((0, 4)), np.zeros((0, 4)), np.zeros((0, 4)), np.zeros(0), z, z)
     assert e.value.code == api.RT_ENODEVICE
+
+
+def test_one_hip_runtime_in_the_process():
+    """The library and PyTorch must share one copy of the HIP runtime whatever is imported first (a second copy finds no
+    GPU): checked in a fresh interpreter that loads the library before it imports torch."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from raytracer_amd import api\n"
+            "api.lib()\n"
+            "import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(len(libs), libs)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == "1", out.stdout
