@@ -207,6 +207,13 @@ typedef struct rt_octree {
 } rt_octree;
 int rt_octree_build(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, size_t max_triangles_per_node,
                     size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, rt_octree *out);
+/* The same construction with Subdivide's triangle/box overlap tests and the distribution of the triangle references to
+ * the children (Octree.cpp:146-170,182-192; TriangleBoxIntersection.hpp:153-240) run on HIP device `device`, level by
+ * level; the "keep" selection (Octree.cpp:172-181) and the flattening (Octree.cpp:38-85) stay on the host.  Output
+ * arrays are host memory, bit-identical to rt_octree_build's.  Fails with RT_ENODEVICE without a GPU. */
+int rt_octree_build_device(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, size_t max_triangles_per_node,
+                           size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, int device,
+                           rt_octree *out);
 void rt_octree_free(rt_octree *octree);
 
 #ifdef __cplusplus

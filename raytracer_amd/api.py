@@ -29,7 +29,7 @@ HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = r
 
 EXPORTED_SYMBOLS = [
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_band_row_count", "rt_scene_stats",
-    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_free",
+    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.rt_mesh_free.argtypes = [C.POINTER(rt_mesh)]
         L.rt_mesh_free.restype = None
         L.rt_octree_build.argtypes = [C.POINTER(rt_mesh), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(rt_octree)]
+        L.rt_octree_build_device.argtypes = [C.POINTER(rt_mesh), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(rt_octree)]
         L.rt_octree_free.argtypes = [C.POINTER(rt_octree)]
         L.rt_octree_free.restype = None
         _lib = L
@@ -170,7 +171,8 @@ class Octree:
     """Octree(meshes, depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_after) -- Octree.hpp:27-36."""
 
     def __init__(self, meshes, depth_limit: int = 18, max_triangles_per_node: int = 10, max_triangles_per_leaf: int = 6,
-                 keep_triangles_after_this_many_overlaps: int = 6):
+                 keep_triangles_after_this_many_overlaps: int = 6, *, device: int | None = None):
+        """device=None: the host builder; device=i: the same construction with the overlap tests on GPU i (identical arrays)."""
         arr = (rt_mesh * max(1, len(meshes)))()
         keep = []
         for i, me in enumerate(meshes):
@@ -179,7 +181,10 @@ class Octree:
             arr[i].vertices = v.ctypes.data_as(C.POINTER(C.c_float)); arr[i].normals = n.ctypes.data_as(C.POINTER(C.c_float))
             arr[i].triangles = t.ctypes.data_as(C.POINTER(C.c_uint32)); arr[i].n_vert = len(v); arr[i].n_tri = len(t)
         o = rt_octree()
-        _check(lib().rt_octree_build(arr, len(meshes), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, C.byref(o)))
+        if device is None:
+            _check(lib().rt_octree_build(arr, len(meshes), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, C.byref(o)))
+        else:
+            _check(lib().rt_octree_build_device(arr, len(meshes), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, int(device), C.byref(o)))
         try:
             self.m_vertecies = np.ctypeslib.as_array(o.vertices, (o.n_vert, 4)).copy() if o.n_vert else np.zeros((0, 4), np.float32)
             self.m_normals = np.ctypeslib.as_array(o.normals, (o.n_vert, 4)).copy() if o.n_vert else np.zeros((0, 4), np.float32)

@@ -17,78 +17,13 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/rt_hotpath.h"
+#include "rt_build_internal.h"
 
 extern "C" const char *rt_last_error(void);
 
 namespace rt_host {
 
-struct Tri { uint32_t a, b, c, material; };
-
-// ---- arithmetic of the glm calls the reference makes -------------------------------------------------------
-static inline float dot_xyz(const float p[3], const float q[3]) { const float x = p[0] * q[0], y = p[1] * q[1], z = p[2] * q[2]; return (x + y) + z; }
-static inline void cross_glm(const float p[3], const float q[3], float out[3]) {
-    out[0] = p[1] * q[2] - q[1] * p[2];
-    out[1] = p[2] * q[0] - q[2] * p[0];
-    out[2] = p[0] * q[1] - q[0] * p[1];
-}
 static inline void normalize_glm(float v[3]) { const float inv = 1.0f / std::sqrt(dot_xyz(v, v)); v[0] *= inv; v[1] *= inv; v[2] *= inv; }
-
-// ---- triangle / box separating-axis test (TriangleBoxIntersection.hpp:153-240) -----------------------------
-// Axis cross(edge, unit axis k): the two non-k coordinates (i, j) of the edge weight the (i, j) coordinates of two
-// of the translated vertices; which two vertices are projected is fixed per (edge, axis) in the reference.
-struct AxisPlan { int p, q; };   // vertex indices projected for (edge e, axis k)
-static const AxisPlan kPlan[3][3] = {
-    {{0, 2}, {0, 2}, {1, 2}},   // edge 0: X01, Y02, Z12
-    {{0, 2}, {0, 2}, {0, 1}},   // edge 1: X01, Y02, Z0
-    {{0, 1}, {0, 1}, {1, 2}},   // edge 2: X2,  Y1,  Z12
-};
-static inline float project(int axis, const float e[3], const float v[3]) {
-    switch (axis) {
-    case 0: return e[2] * v[1] - e[1] * v[2];     // a*v.y - b*v.z with (a,b) = (e.z, e.y)
-    case 1: return -e[2] * v[0] + e[0] * v[2];    // -a*v.x + b*v.z with (a,b) = (e.z, e.x)
-    default: return e[1] * v[0] - e[0] * v[1];    // a*v.x - b*v.y with (a,b) = (e.y, e.x)
-    }
-}
-static inline float radius(int axis, const float fe[3], const float h[3]) {
-    switch (axis) {
-    case 0: return fe[2] * h[1] + fe[1] * h[2];
-    case 1: return fe[2] * h[0] + fe[0] * h[2];
-    default: return fe[1] * h[0] + fe[0] * h[1];
-    }
-}
-static bool triangle_overlaps_box(const float center[3], const float h[3], const float t0[3], const float t1[3], const float t2[3]) {
-    float v[3][3], e[3][3];
-    for (int k = 0; k < 3; k++) { v[0][k] = t0[k] - center[k]; v[1][k] = t1[k] - center[k]; v[2][k] = t2[k] - center[k]; }
-    for (int k = 0; k < 3; k++) { e[0][k] = v[1][k] - v[0][k]; e[1][k] = v[2][k] - v[1][k]; e[2][k] = v[0][k] - v[2][k]; }
-    for (int ed = 0; ed < 3; ed++) {
-        const float fe[3] = {std::fabs(e[ed][0]), std::fabs(e[ed][1]), std::fabs(e[ed][2])};
-        for (int ax = 0; ax < 3; ax++) {
-            const float pa = project(ax, e[ed], v[kPlan[ed][ax].p]);
-            const float pb = project(ax, e[ed], v[kPlan[ed][ax].q]);
-            const float lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
-            const float rad = radius(ax, fe, h);
-            if (lo > rad || hi < -rad) return false;
-        }
-    }
-    for (int k = 0; k < 3; k++) {
-        float lo = v[0][k], hi = v[0][k];
-        if (v[1][k] < lo) lo = v[1][k];
-        if (v[1][k] > hi) hi = v[1][k];
-        if (v[2][k] < lo) lo = v[2][k];
-        if (v[2][k] > hi) hi = v[2][k];
-        if (lo > h[k] || hi < -h[k]) return false;
-    }
-    float nrm[3];
-    cross_glm(e[0], e[1], nrm);
-    float near_[3], far_[3];
-    for (int k = 0; k < 3; k++) {
-        if (nrm[k] > 0.0f) { near_[k] = -h[k] - v[0][k]; far_[k] = h[k] - v[0][k]; }
-        else { near_[k] = h[k] - v[0][k]; far_[k] = -h[k] - v[0][k]; }
-    }
-    if (dot_xyz(nrm, near_) > 0.0f) return false;
-    return dot_xyz(nrm, far_) >= 0.0f;
-}
 
 // ---- octree ------------------------------------------------------------------------------------------------
 struct BuildNode {
@@ -107,23 +42,15 @@ struct Split {           // result of splitting one node, produced by a worker, 
     std::vector<Tri> kept;
 };
 
-struct Params { size_t depth_limit, max_per_node, max_per_leaf, keep_after; };
-
 static void split_node(const BuildNode &n, const float *verts, const Params &P, Split &out) {
     // Octree.cpp:119-124: stop at the depth limit (depth counted from 1 at the root) or when small enough
     if ((size_t)n.depth + 1 >= P.depth_limit || n.tris.size() <= P.max_per_leaf) return;
     out.did_split = true;
-    float mid[3];
-    for (int k = 0; k < 3; k++) mid[k] = (n.lo[k] + n.hi[k]) / 2.0f;   // Octree.cpp:130
     float center[8][3], halfsz[8][3];
-    for (int i = 0; i < 8; i++)
-        for (int k = 0; k < 3; k++) {
-            const bool upper = (i >> k) & 1;
-            out.clo[i][k] = upper ? mid[k] : n.lo[k];
-            out.chi[i][k] = upper ? n.hi[k] : mid[k];
-            center[i][k] = (out.clo[i][k] + out.chi[i][k]) / 2.0f;   // Octree.cpp:19
-            halfsz[i][k] = (out.chi[i][k] - out.clo[i][k]) / 2.0f;   // Octree.cpp:20
-        }
+    for (int i = 0; i < 8; i++) {
+        child_box(n.lo, n.hi, i, out.clo[i], out.chi[i]);
+        box_centre_half(out.clo[i], out.chi[i], center[i], halfsz[i]);
+    }
     struct Cand { uint8_t mask, count; Tri tri; };
     std::vector<Cand> cands;
     for (const Tri &t : n.tris) {
@@ -141,11 +68,9 @@ static void split_node(const BuildNode &n, const float *verts, const Params &P, 
         for (int k = 0; k < 8; k++) if (cands[i].mask & (1u << k)) out.child_tris[k].push_back(cands[i].tri);
 }
 
-static int build_octree(const float *verts, size_t n_vert, const std::vector<Tri> &all, const Params &P, rt_octree *out) {
-    (void)n_vert;
-    std::vector<BuildNode> pool(1);
+void root_bounds(const float *verts, const std::vector<Tri> &all, float lo[3], float hi[3]) {
     const float inf = std::numeric_limits<float>::infinity();
-    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    for (int k = 0; k < 3; k++) { lo[k] = inf; hi[k] = -inf; }
     for (const Tri &t : all)   // Octree.cpp:234-246, min/max as glm defines them
         for (uint32_t vi : {t.a, t.b, t.c})
             for (int k = 0; k < 3; k++) {
@@ -153,6 +78,13 @@ static int build_octree(const float *verts, size_t n_vert, const std::vector<Tri
                 lo[k] = x < lo[k] ? x : lo[k];
                 hi[k] = hi[k] < x ? x : hi[k];
             }
+}
+
+static int build_octree(const float *verts, size_t n_vert, const std::vector<Tri> &all, const Params &P, rt_octree *out) {
+    (void)n_vert;
+    std::vector<BuildNode> pool(1);
+    float lo[3], hi[3];
+    root_bounds(verts, all, lo, hi);
     for (int k = 0; k < 3; k++) { pool[0].lo[k] = lo[k]; pool[0].hi[k] = hi[k]; }
     pool[0].tris = all;
     size_t max_depth = 0;
@@ -332,10 +264,33 @@ static int mesh_from(const float *pos, const float *file_nrm, size_t n, const ui
     return RT_OK;
 }
 
-}  // namespace rt_host
+int merge_meshes(const rt_mesh *meshes, size_t n_meshes, float **verts_out, float **norms_out, size_t *n_vert, std::vector<Tri> &all) {
+    size_t nv = 0, nt = 0;
+    for (size_t i = 0; i < n_meshes; i++) { nv += meshes[i].n_vert; nt += meshes[i].n_tri; }
+    if (nv > 0xFFFFFFFFull || nt > 0xFFFFFFFFull) return rt_internal_set_error(RT_ELIMIT, "scene too large for 32-bit indices");
+    float *verts = (float *)malloc(std::max<size_t>(1, nv) * 16), *norms = (float *)malloc(std::max<size_t>(1, nv) * 16);
+    if (!verts || !norms) { free(verts); free(norms); return rt_internal_set_error(RT_ENOMEM, "out of memory"); }
+    all.clear();
+    all.reserve(nt);
+    size_t base = 0;
+    for (size_t i = 0; i < n_meshes; i++) {   // Octree.cpp:221-233
+        const rt_mesh &m = meshes[i];
+        if (m.n_vert) {
+            memcpy(verts + 4 * base, m.vertices, m.n_vert * 16);
+            memcpy(norms + 4 * base, m.normals, m.n_vert * 16);
+        }
+        for (size_t t = 0; t < m.n_tri; t++) {
+            const uint32_t *q = m.triangles + 4 * t;
+            if (q[0] >= m.n_vert || q[1] >= m.n_vert || q[2] >= m.n_vert) { free(verts); free(norms); return rt_internal_set_error(RT_ESCENE, "triangle indexes a vertex that does not exist"); }
+            all.push_back({q[0] + (uint32_t)base, q[1] + (uint32_t)base, q[2] + (uint32_t)base, q[3]});
+        }
+        base += m.n_vert;
+    }
+    *verts_out = verts; *norms_out = norms; *n_vert = nv;
+    return RT_OK;
+}
 
-// error text is kept by rt_api.cpp; this translation unit reports through a small hook
-extern "C" int rt_internal_set_error(int code, const char *msg);
+}  // namespace rt_host
 
 extern "C" {
 
@@ -380,27 +335,11 @@ int rt_octree_build(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, 
                     size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, rt_octree *out) {
     if (!out || (n_meshes && !meshes)) return rt_internal_set_error(RT_EINVAL, "null argument");
     if (depth_limit > RT_MAX_TREE_DEPTH) return rt_internal_set_error(RT_ELIMIT, "depth_limit beyond RT_MAX_TREE_DEPTH");
-    size_t nv = 0, nt = 0;
-    for (size_t i = 0; i < n_meshes; i++) { nv += meshes[i].n_vert; nt += meshes[i].n_tri; }
-    if (nv > 0xFFFFFFFFull || nt > 0xFFFFFFFFull) return rt_internal_set_error(RT_ELIMIT, "scene too large for 32-bit indices");
-    float *verts = (float *)malloc(std::max<size_t>(1, nv) * 16), *norms = (float *)malloc(std::max<size_t>(1, nv) * 16);
-    if (!verts || !norms) { free(verts); free(norms); return rt_internal_set_error(RT_ENOMEM, "out of memory"); }
+    float *verts = nullptr, *norms = nullptr;
+    size_t nv = 0;
     std::vector<rt_host::Tri> all;
-    all.reserve(nt);
-    size_t base = 0;
-    for (size_t i = 0; i < n_meshes; i++) {   // Octree.cpp:221-233
-        const rt_mesh &m = meshes[i];
-        if (m.n_vert) {
-            memcpy(verts + 4 * base, m.vertices, m.n_vert * 16);
-            memcpy(norms + 4 * base, m.normals, m.n_vert * 16);
-        }
-        for (size_t t = 0; t < m.n_tri; t++) {
-            const uint32_t *q = m.triangles + 4 * t;
-            if (q[0] >= m.n_vert || q[1] >= m.n_vert || q[2] >= m.n_vert) { free(verts); free(norms); return rt_internal_set_error(RT_ESCENE, "triangle indexes a vertex that does not exist"); }
-            all.push_back({q[0] + (uint32_t)base, q[1] + (uint32_t)base, q[2] + (uint32_t)base, q[3]});
-        }
-        base += m.n_vert;
-    }
+    int mrc = rt_host::merge_meshes(meshes, n_meshes, &verts, &norms, &nv, all);
+    if (mrc) return mrc;
     rt_host::Params P{depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps};
     int rc = rt_host::build_octree(verts, nv, all, P, out);
     if (rc) { free(verts); free(norms); return rt_internal_set_error(rc, "out of memory"); }
