@@ -8,15 +8,17 @@
 //   classify_kernel   one lane per pair: the eight child overlap tests -> overlap mask and count
 //   (prefix sums)     an 8-wide exclusive sum over the masks of the pairs that go down (rocPRIM): the rank of a pair
 //                     among the earlier pairs of its node that enter the same child = its place in that child's list
-//   totals_kernel     per node and octant the number of such pairs
-//   scatter_kernel    writes the next level's pairs; child_boxes_kernel the next level's boxes
+//   child_sizes_kernel per node and octant the size of the child's list; a second prefix sum over these gives every
+//                     non-empty child its index and its first pair in the next level
+//   next_level_kernel / scatter_kernel / tail_kernel   write the next level's segments, boxes and pairs
 // Triangles that overlap `keep_after` or more children are the reference's "keep" candidates (Octree.cpp:167-181): at
 // most max_per_node of them stay in the node, chosen by std::partial_sort on the overlap count alone, whose order among
 // equal counts is whatever the library's heap leaves.  They are few, so they are copied to the host, ordered there by
 // the same library call on the same sequence, and the ones pushed down are appended to the children's lists
-// (tail_kernel) exactly where the reference appends them.  The host also keeps the tree's shape (a few words per
-// node) and flattens it (Octree.cpp:38-85); the leaves' references are gathered into pre-order on the device
-// (emit_kernel) and come back in one copy.
+// (tail_kernel) exactly where the reference appends them.  Per-node data never visits the host otherwise: the
+// flattening (Octree.cpp:38-85) is a bottom-up pass for the sizes of the subtrees (subtree_kernel) and a top-down pass
+// that places every node's words and references in pre-order (place_kernel, emit_kernel, emit_kept_kernel); the two
+// flattened arrays come back in one copy each.
 //
 // Built WITHOUT -fgpu-flush-denormals-to-zero: the reference's builder runs on the CPU with denormals preserved.
 #include <hip/hip_runtime.h>
@@ -42,7 +44,7 @@ constexpr int BLOCK = 256;
 struct Box { float lo[3], hi[3]; };
 struct Count8 { uint32_t c[8]; };
 struct CandRec { uint32_t pair, node, cls; Tri tri; };     // a keep candidate, copied to the host
-struct PushRec { uint32_t dest, node; Tri tri; };          // a candidate pushed down: place in the next level's pair list
+struct PushRec { uint32_t dest, node; Tri tri; };          // (rank, slot or node, triangle) of a candidate pushed down or kept
 
 struct AddCount8 {
     __host__ __device__ Count8 operator()(const Count8 &a, const Count8 &b) const {
@@ -59,6 +61,17 @@ struct GoesDown {      // class word -> one count per octant, for the pairs that
         return r;
     }
 };
+struct Place { uint32_t first_pair, index; uint32_t overflow = 0; };   // of a child slot: first pair and node index in the next level
+struct AddPlace {
+    __host__ __device__ Place operator()(const Place &a, const Place &b) const {
+        Place r;
+        const unsigned long long p = (unsigned long long)a.first_pair + b.first_pair;
+        r.first_pair = (uint32_t)p; r.index = a.index + b.index;
+        r.overflow = a.overflow | b.overflow | (p >= 0x7FFFFFFFull ? 1u : 0u);
+        return r;
+    }
+};
+struct SizeToPlace { __host__ __device__ Place operator()(uint32_t size) const { Place r; r.first_pair = size; r.index = size ? 1u : 0u; r.overflow = 0; return r; } };
 struct IsCandidate { __host__ __device__ uint8_t operator()(uint16_t cls) const { return (uint8_t)((cls & CAND_BIT) ? 1 : 0); } };
 
 // Octree.cpp:119-124: a node is split unless it sits at the depth limit or holds few enough triangles
@@ -85,11 +98,22 @@ __global__ __launch_bounds__(BLOCK) void classify_kernel(const Tri *__restrict__
     cls[i] = (uint16_t)(mask | (count << 8) | (count >= keep_after ? CAND_BIT : 0u));   // Octree.cpp:163
 }
 
-__global__ __launch_bounds__(BLOCK) void totals_kernel(const Count8 *__restrict__ rank, const uint32_t *__restrict__ seg, uint32_t n_nodes, uint32_t *__restrict__ totals) {
+// size of every child's list before the pushed-down candidates are added: the pairs of the node that enter octant o
+__global__ __launch_bounds__(BLOCK) void child_sizes_kernel(const Count8 *__restrict__ rank, const uint32_t *__restrict__ seg, uint32_t n_nodes, uint32_t *__restrict__ down,
+                                                            uint32_t *__restrict__ sizes) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_nodes * 8u) return;
+    if (i > n_nodes * 8u) return;
+    if (i == n_nodes * 8u) { sizes[i] = 0; return; }      // the prefix sum runs over one entry more
     const uint32_t node = i >> 3, o = i & 7u;
-    totals[i] = rank[seg[node + 1]].c[o] - rank[seg[node]].c[o];
+    const uint32_t n = rank[seg[node + 1]].c[o] - rank[seg[node]].c[o];
+    down[i] = n;
+    sizes[i] = n;
+}
+
+// pushed-down candidates: (node * 8 + octant, how many), every slot at most once
+__global__ __launch_bounds__(BLOCK) void add_pushed_kernel(const uint2 *__restrict__ add, uint32_t n, uint32_t *__restrict__ sizes) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j < n) sizes[add[j].x] += add[j].y;
 }
 
 __global__ __launch_bounds__(BLOCK) void candidates_kernel(const uint32_t *__restrict__ cand_idx, uint32_t n_cand, const Tri *__restrict__ pairs,
@@ -101,8 +125,8 @@ __global__ __launch_bounds__(BLOCK) void candidates_kernel(const uint32_t *__res
 }
 
 __global__ __launch_bounds__(BLOCK) void scatter_kernel(const Tri *__restrict__ pairs, const uint32_t *__restrict__ node_of, const uint16_t *__restrict__ cls,
-                                                        const Count8 *__restrict__ rank, const uint32_t *__restrict__ seg, const uint32_t *__restrict__ child_base,
-                                                        const uint32_t *__restrict__ child_node, uint32_t n_pairs, Tri *__restrict__ next_pairs, uint32_t *__restrict__ next_node_of) {
+                                                        const Count8 *__restrict__ rank, const uint32_t *__restrict__ seg, const Place *__restrict__ place,
+                                                        uint32_t n_pairs, Tri *__restrict__ next_pairs, uint32_t *__restrict__ next_node_of) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_pairs) return;
     const uint32_t c = cls[i];
@@ -112,60 +136,125 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(const Tri *__restrict__ 
     const Count8 mine = rank[i], first = rank[seg[node]];
     for (uint32_t o = 0; o < 8; o++)
         if (c & (1u << o)) {
-            const uint32_t dest = child_base[node * 8u + o] + (mine.c[o] - first.c[o]);
+            const Place pl = place[node * 8u + o];
+            const uint32_t dest = pl.first_pair + (mine.c[o] - first.c[o]);
             next_pairs[dest] = t;
-            next_node_of[dest] = child_node[node * 8u + o];
+            next_node_of[dest] = pl.index;
         }
 }
 
-__global__ __launch_bounds__(BLOCK) void tail_kernel(const PushRec *__restrict__ recs, uint32_t n, Tri *__restrict__ next_pairs, uint32_t *__restrict__ next_node_of) {
+__global__ __launch_bounds__(BLOCK) void tail_kernel(const PushRec *__restrict__ recs, uint32_t n, const uint32_t *__restrict__ down, const Place *__restrict__ place,
+                                                     Tri *__restrict__ next_pairs, uint32_t *__restrict__ next_node_of) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= n) return;
-    const PushRec r = recs[j];
-    next_pairs[r.dest] = r.tri;
-    next_node_of[r.dest] = r.node;
+    const PushRec r = recs[j];            // r.dest: rank among the pushed-down candidates of the slot, r.node: the slot
+    const uint32_t dest = place[r.node].first_pair + down[r.node] + r.dest;
+    next_pairs[dest] = r.tri;
+    next_node_of[dest] = place[r.node].index;
 }
 
-__global__ __launch_bounds__(BLOCK) void child_boxes_kernel(const Box *__restrict__ boxes, const uint32_t *__restrict__ child_node, uint32_t n_nodes, Box *__restrict__ next_boxes) {
+// Every non-empty child becomes a node of the next level (Octree.cpp:194-198: empty children are never visited and are
+// dropped when flattening): its segment start, its box (Octree.cpp:130-142) and the parent's link to it.
+__global__ __launch_bounds__(BLOCK) void next_level_kernel(const Box *__restrict__ boxes, const uint32_t *__restrict__ sizes, const Place *__restrict__ place, uint32_t n_nodes,
+                                                           uint32_t *__restrict__ kid, uint32_t *__restrict__ next_seg, Box *__restrict__ next_boxes) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_nodes * 8u) return;
-    const uint32_t child = child_node[i];
-    if (child == NONE) return;
+    if (i > n_nodes * 8u) return;
+    if (i == n_nodes * 8u) { next_seg[place[i].index] = place[i].first_pair; return; }     // totals: closes the last segment
+    if (sizes[i] == 0) { kid[i] = NONE; return; }
+    const uint32_t child = place[i].index;
+    kid[i] = child;
+    next_seg[child] = place[i].first_pair;
     const Box b = boxes[i >> 3];
     Box out;
     rt_host::child_box(b.lo, b.hi, (int)(i & 7u), out.lo, out.hi);
     next_boxes[child] = out;
 }
 
-// leaves: the node's pairs are its final reference list; leaf_dest[node] is where that list starts in the flattened array
-__global__ __launch_bounds__(BLOCK) void emit_kernel(const Tri *__restrict__ pairs, const uint32_t *__restrict__ node_of, const uint32_t *__restrict__ seg,
-                                                     const uint32_t *__restrict__ leaf_dest, uint32_t n_pairs, Tri *__restrict__ refs) {
+// ---- flattening (Octree.cpp:38-85) -------------------------------------------------------------------------------
+// own[node]: triangles the node itself holds in the flattened tree: what it kept if it was split, its whole list if not
+__global__ __launch_bounds__(BLOCK) void own_kernel(const uint32_t *__restrict__ seg, uint32_t n_nodes, uint32_t max_per_leaf, uint32_t depth_allows_split, uint32_t *__restrict__ own) {
+    const uint32_t n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= n_nodes) return;
+    const uint32_t size = seg[n + 1] - seg[n];
+    own[n] = node_splits(size, max_per_leaf, depth_allows_split) ? 0u : size;
+}
+__global__ __launch_bounds__(BLOCK) void kept_counts_kernel(const uint2 *__restrict__ kept, uint32_t n, uint32_t *__restrict__ own) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j < n) own[kept[j].x] = kept[j].y;
+}
+// words and references of the subtree below (and including) every node; kid == nullptr: the deepest level
+__global__ __launch_bounds__(BLOCK) void subtree_kernel(const uint32_t *__restrict__ own, const uint32_t *__restrict__ kid, const uint2 *__restrict__ below, uint32_t n_nodes,
+                                                        uint2 *__restrict__ sub, uint32_t *__restrict__ overflow) {
+    const uint32_t n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= n_nodes) return;
+    unsigned long long words = 2, refs = own[n];
+    if (kid)
+        for (uint32_t o = 0; o < 8; o++) {
+            const uint32_t k = kid[n * 8u + o];
+            if (k != NONE) { words += 1ull + below[k].x; refs += below[k].y; }
+        }
+    if (words > 0xFFFFFFFFull || refs > 0xFFFFFFFFull) *overflow = 1u;
+    sub[n] = make_uint2((uint32_t)words, (uint32_t)refs);
+}
+// Pre-order: a node's header and child pointers, then its children's subtrees in ascending octant order; its references,
+// then its children's.  at[node] = (first word, first reference) of the node; writes the children's.
+__global__ __launch_bounds__(BLOCK) void place_kernel(const uint32_t *__restrict__ own, const uint32_t *__restrict__ kid, const uint2 *__restrict__ below, const uint2 *__restrict__ at,
+                                                      uint32_t n_nodes, uint2 *__restrict__ at_below, uint32_t *__restrict__ words) {
+    const uint32_t n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= n_nodes) return;
+    const uint2 me = at[n];
+    uint32_t mask = 0, count = 0;
+    if (kid) for (uint32_t o = 0; o < 8; o++) if (kid[n * 8u + o] != NONE) { mask |= 1u << o; count++; }
+    words[me.x] = ((own[n] & 0xFFFFu) << 16) | (mask << 8) | count;     // 16-bit triangle count (Octree.cpp:44)
+    words[me.x + 1] = me.y;
+    uint32_t w = me.x + 2u + count, r = me.y + own[n], j = 0;
+    if (kid)
+        for (uint32_t o = 0; o < 8; o++) {
+            const uint32_t k = kid[n * 8u + o];
+            if (k == NONE) continue;
+            words[me.x + 2u + j++] = w;
+            at_below[k] = make_uint2(w, r);
+            w += below[k].x; r += below[k].y;
+        }
+}
+// references of the nodes that were not split: their pair list, in order
+__global__ __launch_bounds__(BLOCK) void emit_kernel(const Tri *__restrict__ pairs, const uint32_t *__restrict__ node_of, const uint32_t *__restrict__ seg, const uint2 *__restrict__ at,
+                                                     uint32_t n_pairs, uint32_t max_per_leaf, uint32_t depth_allows_split, Tri *__restrict__ refs) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_pairs) return;
-    const uint32_t node = node_of[i], dest = leaf_dest[node];
-    if (dest != NONE) refs[dest + (i - seg[node])] = pairs[i];
+    const uint32_t node = node_of[i], first = seg[node];
+    if (!node_splits(seg[node + 1] - first, max_per_leaf, depth_allows_split)) refs[at[node].y + (i - first)] = pairs[i];
+}
+// references of the split nodes: the candidates they kept (r.node: the node, r.dest: rank in its kept list)
+__global__ __launch_bounds__(BLOCK) void emit_kept_kernel(const PushRec *__restrict__ kept, uint32_t n, const uint2 *__restrict__ at, Tri *__restrict__ refs) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j < n) refs[at[kept[j].node].y + kept[j].dest] = kept[j].tri;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct DevBuf {
     void *p = nullptr;
+    size_t cap = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p) { o.p = nullptr; }
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 1); }
+    hipError_t alloc(size_t bytes) {         // grows only: the per-level scratch buffers are reused from level to level
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes ? bytes + bytes / 4 : 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
     template <class T> T *as() const { return (T *)p; }
 };
 
-struct Level {                       // one tree level: host-side shape + the device arrays the final gather reads
+struct Level {                       // what stays on the device of one tree level until the tree is flattened
     uint32_t n_nodes = 0, n_pairs = 0;
-    std::vector<uint32_t> seg;       // [n_nodes + 1] first pair of each node
-    std::vector<uint8_t> split;      // node was subdivided
-    std::vector<uint32_t> kid;       // [n_nodes * 8] index in the next level, NONE for an empty child
-    std::vector<uint32_t> kept_off;  // [n_nodes + 1] into `kept` (split nodes: the triangles that stay in the node)
-    std::vector<Tri> kept;
-    DevBuf pairs, node_of, seg_d;
+    bool depth_allows_split = false;
+    DevBuf pairs, node_of, seg, kid, own, sub, at;
+    std::vector<PushRec> kept;       // the triangles split nodes kept: (node, rank, triangle)
 };
 
 inline uint32_t grid_for(size_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
@@ -177,9 +266,9 @@ struct Cand { uint8_t mask, count; uint32_t slot; };   // slot: index into the l
 struct PhaseClock {          // RT_BUILD_TRACE=1: wall time per phase on stderr
     bool on = getenv("RT_BUILD_TRACE") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[6] = {0, 0, 0, 0, 0, 0};
     void lap(int k) { if (!on) return; auto n = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; }
-    void report() { if (on) fprintf(stderr, "device octree build ms: setup %.1f | kernels+readback %.1f | host ordering %.1f | scatter %.1f | flatten %.1f | emit+copy %.1f\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]); }
+    void report() { if (on) fprintf(stderr, "device octree build ms: upload %.1f | classify+rank+candidates %.1f | candidate ordering (host) %.1f | next level %.1f | flatten %.1f | copy back %.1f\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]); }
 };
 
 int build_on_device(const float *verts, size_t n_vert, const std::vector<Tri> &all, const rt_host::Params &P, rt_octree *out) {
@@ -200,52 +289,48 @@ int build_on_device(const float *verts, size_t n_vert, const std::vector<Tri> &a
     {   // level 0: the root holds every triangle (Octree.cpp:248-250)
         auto L = std::make_unique<Level>();
         L->n_nodes = 1; L->n_pairs = (uint32_t)all.size();
-        L->seg = {0u, L->n_pairs};
+        const uint32_t seg0[2] = {0u, L->n_pairs};
+        Box rb;
+        for (int k = 0; k < 3; k++) { rb.lo[k] = root_lo[k]; rb.hi[k] = root_hi[k]; }
         HIP_OK(L->pairs.alloc((size_t)L->n_pairs * sizeof(Tri)));
         HIP_OK(L->node_of.alloc((size_t)L->n_pairs * 4));
+        HIP_OK(L->seg.alloc(8));
+        HIP_OK(boxes.alloc(sizeof(Box)));
         if (L->n_pairs) {
             HIP_OK(hipMemcpyAsync(L->pairs.p, all.data(), (size_t)L->n_pairs * sizeof(Tri), hipMemcpyHostToDevice, st));
             HIP_OK(hipMemsetAsync(L->node_of.p, 0, (size_t)L->n_pairs * 4, st));
         }
-        Box rb;
-        for (int k = 0; k < 3; k++) { rb.lo[k] = root_lo[k]; rb.hi[k] = root_hi[k]; }
-        HIP_OK(boxes.alloc(sizeof(Box)));
+        HIP_OK(hipMemcpyAsync(L->seg.p, seg0, 8, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(boxes.p, &rb, sizeof rb, hipMemcpyHostToDevice, st));
-        HIP_OK(hipStreamSynchronize(st));      // rb is a stack object
+        HIP_OK(hipStreamSynchronize(st));      // seg0 and rb are stack objects
         levels.push_back(std::move(L));
     }
-
     clock.lap(0);
+
     size_t max_depth = 0;
-    DevBuf cls, rank, totals_d, cand_idx, cand_n, cand_recs, scan_tmp, child_base_d, child_node_d, push_d;
-    std::vector<uint32_t> totals, child_base, child_node;
+    const uint32_t keep_after = (uint32_t)std::min<size_t>(P.keep_after, 9), max_leaf = (uint32_t)std::min<size_t>(P.max_per_leaf, 0xFFFFFFFFu);
+    DevBuf cls, rank, down, sizes, place, cand_idx, cand_n, cand_recs, scan_tmp, add_d, push_d, kept_d;
     std::vector<CandRec> cand_host;
     std::vector<PushRec> pushes;
+    std::vector<uint2> adds, kept_counts;
     std::vector<Cand> cands;
+    HIP_OK(cand_n.alloc(4));
     for (uint32_t depth = 0;; depth++) {
         Level &L = *levels.back();
         const uint32_t n_nodes = L.n_nodes, n_pairs = L.n_pairs;
         // Octree.cpp:119-125: m_max_depth is raised for every visited node below the depth limit
-        const bool depth_allows_split = (size_t)depth + 1 < P.depth_limit;
-        if (depth_allows_split) max_depth = std::max(max_depth, (size_t)depth + 1);
-        L.split.assign(n_nodes, 0);
-        L.kid.assign((size_t)n_nodes * 8, NONE);
-        L.kept_off.assign((size_t)n_nodes + 1, 0);
-        HIP_OK(L.seg_d.alloc(((size_t)n_nodes + 1) * 4));
-        HIP_OK(hipMemcpyAsync(L.seg_d.p, L.seg.data(), ((size_t)n_nodes + 1) * 4, hipMemcpyHostToDevice, st));
-        bool any_split = false;
-        for (uint32_t n = 0; n < n_nodes; n++) {
-            L.split[n] = depth_allows_split && (size_t)(L.seg[n + 1] - L.seg[n]) > P.max_per_leaf;
-            any_split = any_split || L.split[n];
-        }
-        if (!any_split) { HIP_OK(hipStreamSynchronize(st)); break; }
+        L.depth_allows_split = (size_t)depth + 1 < P.depth_limit;
+        if (L.depth_allows_split) max_depth = std::max(max_depth, (size_t)depth + 1);
+        HIP_OK(L.own.alloc((size_t)n_nodes * 4));
+        own_kernel<<<grid_for(n_nodes), BLOCK, 0, st>>>(L.seg.as<uint32_t>(), n_nodes, max_leaf, L.depth_allows_split ? 1u : 0u, L.own.as<uint32_t>());
+        HIP_OK(hipGetLastError());
+        if (!L.depth_allows_split || n_pairs == 0) break;
 
-        // ---- classify, rank, count --------------------------------------------------------------------------------
+        // ---- classify, rank, child sizes ---------------------------------------------------------------------------
         HIP_OK(cls.alloc(((size_t)n_pairs + 1) * 2));
         HIP_OK(hipMemsetAsync((char *)cls.p + (size_t)n_pairs * 2, 0, 2, st));     // the sum runs over n_pairs + 1 entries
-        const uint32_t keep_after = (uint32_t)std::min<size_t>(P.keep_after, 9), max_leaf = (uint32_t)std::min<size_t>(P.max_per_leaf, 0xFFFFFFFFu);
-        classify_kernel<<<grid_for(n_pairs), BLOCK, 0, st>>>(L.pairs.as<Tri>(), L.node_of.as<uint32_t>(), boxes.as<Box>(), L.seg_d.as<uint32_t>(), d_verts.as<float4>(),
-                                                              n_pairs, keep_after, max_leaf, depth_allows_split ? 1u : 0u, cls.as<uint16_t>());
+        classify_kernel<<<grid_for(n_pairs), BLOCK, 0, st>>>(L.pairs.as<Tri>(), L.node_of.as<uint32_t>(), boxes.as<Box>(), L.seg.as<uint32_t>(), d_verts.as<float4>(),
+                                                              n_pairs, keep_after, max_leaf, 1u, cls.as<uint16_t>());
         HIP_OK(hipGetLastError());
         HIP_OK(rank.alloc(((size_t)n_pairs + 1) * sizeof(Count8)));
         {
@@ -255,12 +340,14 @@ int build_on_device(const float *verts, size_t n_vert, const std::vector<Tri> &a
             HIP_OK(scan_tmp.alloc(bytes));
             HIP_OK(hipcub::DeviceScan::ExclusiveScan(scan_tmp.p, bytes, in, rank.as<Count8>(), AddCount8(), Count8{}, (int)(n_pairs + 1), st));
         }
-        HIP_OK(totals_d.alloc((size_t)n_nodes * 32));
-        totals_kernel<<<grid_for((size_t)n_nodes * 8), BLOCK, 0, st>>>(rank.as<Count8>(), L.seg_d.as<uint32_t>(), n_nodes, totals_d.as<uint32_t>());
+        const size_t slots = (size_t)n_nodes * 8;
+        if (slots + 1 >= 0x7FFFFFFFull) return rt_internal_set_error(RT_ELIMIT, "a tree level has too many nodes for the device builder");
+        HIP_OK(down.alloc(slots * 4));
+        HIP_OK(sizes.alloc((slots + 1) * 4));
+        child_sizes_kernel<<<grid_for(slots + 1), BLOCK, 0, st>>>(rank.as<Count8>(), L.seg.as<uint32_t>(), n_nodes, down.as<uint32_t>(), sizes.as<uint32_t>());
         HIP_OK(hipGetLastError());
         // ---- the keep candidates, in pair order, to the host ---------------------------------------------------------
         HIP_OK(cand_idx.alloc((size_t)n_pairs * 4));
-        HIP_OK(cand_n.alloc(4));
         {
             hipcub::TransformInputIterator<uint8_t, IsCandidate, const uint16_t *> flags(cls.as<uint16_t>(), IsCandidate());
             hipcub::CountingInputIterator<uint32_t> idx(0u);
@@ -271,8 +358,6 @@ int build_on_device(const float *verts, size_t n_vert, const std::vector<Tri> &a
         }
         uint32_t n_cand = 0;
         HIP_OK(hipMemcpyAsync(&n_cand, cand_n.p, 4, hipMemcpyDeviceToHost, st));
-        totals.resize((size_t)n_nodes * 8);
-        HIP_OK(hipMemcpyAsync(totals.data(), totals_d.p, (size_t)n_nodes * 32, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         cand_host.resize(n_cand);
         if (n_cand) {
@@ -282,154 +367,137 @@ int build_on_device(const float *verts, size_t n_vert, const std::vector<Tri> &a
             HIP_OK(hipMemcpyAsync(cand_host.data(), cand_recs.p, (size_t)n_cand * sizeof(CandRec), hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));
         }
-
         clock.lap(1);
-        // ---- host: who stays, who is pushed down, and the shape of the next level -----------------------------------
+
+        // ---- host: which candidates stay and which are pushed down ----------------------------------------------------
         // Octree.cpp:172-181: the library's partial sort, ordering on the overlap count only, on the candidates in the order
         // the reference met them; the first max_per_node stay, the rest go to the children after everything else.
-        std::vector<uint32_t> pushed_count((size_t)n_nodes * 8, 0);
-        struct Pushed { uint32_t node, slot; };
-        std::vector<Pushed> pushed_order;
-        L.kept.clear();
-        {
-            size_t j = 0;
-            for (uint32_t n = 0; n < n_nodes; n++) {
-                L.kept_off[n] = (uint32_t)L.kept.size();
-                cands.clear();
-                while (j < cand_host.size() && cand_host[j].node == n) { cands.push_back({(uint8_t)(cand_host[j].cls & 0xFFu), (uint8_t)((cand_host[j].cls >> 8) & 0xFu), (uint32_t)j}); j++; }
-                if (cands.empty()) continue;
-                if (cands.size() > P.max_per_node)
-                    std::partial_sort(cands.begin(), cands.begin() + (std::ptrdiff_t)P.max_per_node, cands.end(), [](const Cand &x, const Cand &y) { return x.count > y.count; });
-                const size_t keep = std::min(cands.size(), P.max_per_node);
-                for (size_t i = 0; i < keep; i++) L.kept.push_back(cand_host[cands[i].slot].tri);
-                for (size_t i = P.max_per_node; i < cands.size(); i++) {
-                    pushed_order.push_back({n, cands[i].slot});
-                    for (int o = 0; o < 8; o++) if (cands[i].mask & (1u << o)) pushed_count[(size_t)n * 8 + o]++;
-                }
-            }
-            L.kept_off[n_nodes] = (uint32_t)L.kept.size();
+        pushes.clear(); adds.clear(); kept_counts.clear();
+        for (size_t j = 0; j < cand_host.size();) {
+            const uint32_t n = cand_host[j].node;
+            cands.clear();
+            for (; j < cand_host.size() && cand_host[j].node == n; j++) cands.push_back({(uint8_t)(cand_host[j].cls & 0xFFu), (uint8_t)((cand_host[j].cls >> 8) & 0xFu), (uint32_t)j});
+            if (cands.size() > P.max_per_node)
+                std::partial_sort(cands.begin(), cands.begin() + (std::ptrdiff_t)P.max_per_node, cands.end(), [](const Cand &x, const Cand &y) { return x.count > y.count; });
+            const size_t keep = std::min(cands.size(), P.max_per_node);
+            for (size_t i = 0; i < keep; i++) L.kept.push_back({(uint32_t)i, n, cand_host[cands[i].slot].tri});
+            if (keep) kept_counts.push_back(make_uint2(n, (uint32_t)keep));
+            uint32_t fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = P.max_per_node; i < cands.size(); i++)
+                for (uint32_t o = 0; o < 8; o++)
+                    if (cands[i].mask & (1u << o)) pushes.push_back({fill[o]++, n * 8u + o, cand_host[cands[i].slot].tri});
+            for (uint32_t o = 0; o < 8; o++) if (fill[o]) adds.push_back(make_uint2(n * 8u + o, fill[o]));
         }
-        auto N = std::make_unique<Level>();
-        child_base.assign((size_t)n_nodes * 8, 0);
-        child_node.assign((size_t)n_nodes * 8, NONE);
-        N->seg.push_back(0u);
-        uint64_t next_pairs = 0;
-        for (uint32_t n = 0; n < n_nodes; n++) {
-            if (!L.split[n]) continue;
-            for (int o = 0; o < 8; o++) {
-                const size_t q = (size_t)n * 8 + o;
-                const uint32_t size = totals[q] + pushed_count[q];
-                if (size == 0) continue;                 // Octree.cpp:194-198: empty children are never visited (and are dropped when flattening)
-                child_base[q] = (uint32_t)next_pairs;
-                child_node[q] = N->n_nodes;
-                L.kid[q] = N->n_nodes;
-                N->n_nodes++;
-                next_pairs += size;
-                if (next_pairs >= 0x7FFFFFFFull) return rt_internal_set_error(RT_ELIMIT, "a tree level holds too many triangle references for the device builder");
-                N->seg.push_back((uint32_t)next_pairs);
-            }
-        }
-        N->n_pairs = (uint32_t)next_pairs;
-        pushes.clear();
-        {
-            std::vector<uint32_t> tail_fill((size_t)n_nodes * 8, 0);
-            for (const Pushed &pd : pushed_order) {
-                const CandRec &c = cand_host[pd.slot];
-                for (int o = 0; o < 8; o++)
-                    if (c.cls & (1u << o)) {
-                        const size_t q = (size_t)pd.node * 8 + o;
-                        pushes.push_back({child_base[q] + totals[q] + tail_fill[q]++, child_node[q], c.tri});
-                    }
-            }
-        }
-        if (N->n_nodes == 0) { HIP_OK(hipStreamSynchronize(st)); break; }
-
         clock.lap(2);
-        // ---- write the next level ---------------------------------------------------------------------------------------
+
+        // ---- the next level -------------------------------------------------------------------------------------------
+        if (!kept_counts.empty()) {
+            HIP_OK(kept_d.alloc(kept_counts.size() * sizeof(uint2)));
+            HIP_OK(hipMemcpyAsync(kept_d.p, kept_counts.data(), kept_counts.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+            kept_counts_kernel<<<grid_for(kept_counts.size()), BLOCK, 0, st>>>(kept_d.as<uint2>(), (uint32_t)kept_counts.size(), L.own.as<uint32_t>());
+            HIP_OK(hipGetLastError());
+        }
+        if (!adds.empty()) {
+            HIP_OK(add_d.alloc(adds.size() * sizeof(uint2)));
+            HIP_OK(hipMemcpyAsync(add_d.p, adds.data(), adds.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+            add_pushed_kernel<<<grid_for(adds.size()), BLOCK, 0, st>>>(add_d.as<uint2>(), (uint32_t)adds.size(), sizes.as<uint32_t>());
+            HIP_OK(hipGetLastError());
+        }
+        HIP_OK(place.alloc((slots + 1) * sizeof(Place)));
+        {
+            hipcub::TransformInputIterator<Place, SizeToPlace, const uint32_t *> in(sizes.as<uint32_t>(), SizeToPlace());
+            size_t bytes = 0;
+            HIP_OK(hipcub::DeviceScan::ExclusiveScan(nullptr, bytes, in, place.as<Place>(), AddPlace(), Place{0u, 0u}, (int)(slots + 1), st));
+            HIP_OK(scan_tmp.alloc(bytes));
+            HIP_OK(hipcub::DeviceScan::ExclusiveScan(scan_tmp.p, bytes, in, place.as<Place>(), AddPlace(), Place{0u, 0u}, (int)(slots + 1), st));
+        }
+        Place total{0u, 0u};
+        HIP_OK(hipMemcpyAsync(&total, place.as<Place>() + slots, sizeof total, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));      // also: the staging vectors above may be reused now
+        HIP_OK(L.kid.alloc(slots * 4));
+        if (total.index == 0) {                // nothing below this level
+            HIP_OK(hipMemsetAsync(L.kid.p, 0xFF, slots * 4, st));
+            clock.lap(3);
+            break;
+        }
+        if (total.overflow) return rt_internal_set_error(RT_ELIMIT, "a tree level holds too many triangle references for the device builder");
+        auto N = std::make_unique<Level>();
+        N->n_nodes = total.index; N->n_pairs = total.first_pair;
         HIP_OK(N->pairs.alloc((size_t)N->n_pairs * sizeof(Tri)));
         HIP_OK(N->node_of.alloc((size_t)N->n_pairs * 4));
+        HIP_OK(N->seg.alloc(((size_t)N->n_nodes + 1) * 4));
         HIP_OK(next_boxes.alloc((size_t)N->n_nodes * sizeof(Box)));
-        HIP_OK(child_base_d.alloc((size_t)n_nodes * 32));
-        HIP_OK(child_node_d.alloc((size_t)n_nodes * 32));
-        HIP_OK(hipMemcpyAsync(child_base_d.p, child_base.data(), (size_t)n_nodes * 32, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(child_node_d.p, child_node.data(), (size_t)n_nodes * 32, hipMemcpyHostToDevice, st));
-        scatter_kernel<<<grid_for(n_pairs), BLOCK, 0, st>>>(L.pairs.as<Tri>(), L.node_of.as<uint32_t>(), cls.as<uint16_t>(), rank.as<Count8>(), L.seg_d.as<uint32_t>(),
-                                                             child_base_d.as<uint32_t>(), child_node_d.as<uint32_t>(), n_pairs, N->pairs.as<Tri>(), N->node_of.as<uint32_t>());
+        next_level_kernel<<<grid_for(slots + 1), BLOCK, 0, st>>>(boxes.as<Box>(), sizes.as<uint32_t>(), place.as<Place>(), n_nodes, L.kid.as<uint32_t>(), N->seg.as<uint32_t>(), next_boxes.as<Box>());
+        HIP_OK(hipGetLastError());
+        scatter_kernel<<<grid_for(n_pairs), BLOCK, 0, st>>>(L.pairs.as<Tri>(), L.node_of.as<uint32_t>(), cls.as<uint16_t>(), rank.as<Count8>(), L.seg.as<uint32_t>(),
+                                                             place.as<Place>(), n_pairs, N->pairs.as<Tri>(), N->node_of.as<uint32_t>());
         HIP_OK(hipGetLastError());
         if (!pushes.empty()) {
             HIP_OK(push_d.alloc(pushes.size() * sizeof(PushRec)));
             HIP_OK(hipMemcpyAsync(push_d.p, pushes.data(), pushes.size() * sizeof(PushRec), hipMemcpyHostToDevice, st));
-            tail_kernel<<<grid_for(pushes.size()), BLOCK, 0, st>>>(push_d.as<PushRec>(), (uint32_t)pushes.size(), N->pairs.as<Tri>(), N->node_of.as<uint32_t>());
+            tail_kernel<<<grid_for(pushes.size()), BLOCK, 0, st>>>(push_d.as<PushRec>(), (uint32_t)pushes.size(), down.as<uint32_t>(), place.as<Place>(), N->pairs.as<Tri>(), N->node_of.as<uint32_t>());
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipStreamSynchronize(st));  // `pushes` is refilled by the next level
+        }
+        std::swap(boxes.p, next_boxes.p); std::swap(boxes.cap, next_boxes.cap);
+        levels.push_back(std::move(N));
+        clock.lap(3);
+    }
+
+    // ---- flatten: sizes of the subtrees bottom-up, places top-down --------------------------------------------------------
+    DevBuf overflow_d;
+    HIP_OK(overflow_d.alloc(4));
+    HIP_OK(hipMemsetAsync(overflow_d.p, 0, 4, st));
+    for (size_t l = levels.size(); l-- > 0;) {
+        Level &L = *levels[l];
+        HIP_OK(L.sub.alloc((size_t)L.n_nodes * sizeof(uint2)));
+        HIP_OK(L.at.alloc((size_t)L.n_nodes * sizeof(uint2)));
+        const bool last = l + 1 == levels.size();
+        subtree_kernel<<<grid_for(L.n_nodes), BLOCK, 0, st>>>(L.own.as<uint32_t>(), last ? nullptr : L.kid.as<uint32_t>(), last ? nullptr : levels[l + 1]->sub.as<uint2>(), L.n_nodes,
+                                                               L.sub.as<uint2>(), overflow_d.as<uint32_t>());
+        HIP_OK(hipGetLastError());
+    }
+    uint2 total{0u, 0u};
+    uint32_t overflow = 0;
+    HIP_OK(hipMemcpyAsync(&total, levels[0]->sub.p, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&overflow, overflow_d.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemsetAsync(levels[0]->at.p, 0, sizeof(uint2), st));      // the root starts both arrays
+    HIP_OK(hipStreamSynchronize(st));
+    if (overflow) return rt_internal_set_error(RT_ELIMIT, "the flattened octree does not fit 32-bit offsets");
+    const size_t n_words = total.x, n_ref = total.y;
+    DevBuf words_d, refs_d;
+    HIP_OK(words_d.alloc(n_words * 4));
+    HIP_OK(refs_d.alloc(n_ref * sizeof(Tri)));
+    for (size_t l = 0; l < levels.size(); l++) {
+        Level &L = *levels[l];
+        const bool last = l + 1 == levels.size();
+        place_kernel<<<grid_for(L.n_nodes), BLOCK, 0, st>>>(L.own.as<uint32_t>(), last ? nullptr : L.kid.as<uint32_t>(), last ? nullptr : levels[l + 1]->sub.as<uint2>(), L.at.as<uint2>(), L.n_nodes,
+                                                             last ? nullptr : levels[l + 1]->at.as<uint2>(), words_d.as<uint32_t>());
+        HIP_OK(hipGetLastError());
+        if (L.n_pairs) {
+            emit_kernel<<<grid_for(L.n_pairs), BLOCK, 0, st>>>(L.pairs.as<Tri>(), L.node_of.as<uint32_t>(), L.seg.as<uint32_t>(), L.at.as<uint2>(), L.n_pairs, max_leaf,
+                                                                L.depth_allows_split ? 1u : 0u, refs_d.as<Tri>());
             HIP_OK(hipGetLastError());
         }
-        child_boxes_kernel<<<grid_for((size_t)n_nodes * 8), BLOCK, 0, st>>>(boxes.as<Box>(), child_node_d.as<uint32_t>(), n_nodes, next_boxes.as<Box>());
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(st));      // the staging vectors above are reused by the next level
-        std::swap(boxes.p, next_boxes.p);
-        clock.lap(3);
-        levels.push_back(std::move(N));
-    }
-
-    // ---- flatten (Octree.cpp:38-85): pre-order, children in ascending octant order ---------------------------------------
-    std::vector<uint32_t> words;
-    std::vector<std::vector<uint32_t>> leaf_dest(levels.size());
-    for (size_t l = 0; l < levels.size(); l++) leaf_dest[l].assign(levels[l]->n_nodes, NONE);
-    struct KeptCopy { uint32_t level, node, dest; };
-    std::vector<KeptCopy> kept_copies;
-    uint64_t n_ref = 0;
-    struct Visit { uint32_t level, node; size_t parent_slot; };
-    std::vector<Visit> stack = {{0u, 0u, 0u}};
-    while (!stack.empty()) {
-        const Visit v = stack.back();
-        stack.pop_back();
-        const Level &L = *levels[v.level];
-        if (v.parent_slot != 0) words[v.parent_slot] = (uint32_t)words.size();
-        const bool split = !L.split.empty() && L.split[v.node];
-        uint32_t mask = 0, count = 0, n_tris;
-        if (split) {
-            for (int o = 0; o < 8; o++) if (L.kid[(size_t)v.node * 8 + o] != NONE) { mask |= 1u << o; count++; }
-            n_tris = L.kept_off[v.node + 1] - L.kept_off[v.node];
-            if (n_tris) kept_copies.push_back({v.level, v.node, (uint32_t)n_ref});
-        } else {
-            n_tris = L.seg[v.node + 1] - L.seg[v.node];
-            if (n_tris) leaf_dest[v.level][v.node] = (uint32_t)n_ref;
+        if (!L.kept.empty()) {
+            HIP_OK(kept_d.alloc(L.kept.size() * sizeof(PushRec)));
+            HIP_OK(hipMemcpyAsync(kept_d.p, L.kept.data(), L.kept.size() * sizeof(PushRec), hipMemcpyHostToDevice, st));
+            emit_kept_kernel<<<grid_for(L.kept.size()), BLOCK, 0, st>>>(kept_d.as<PushRec>(), (uint32_t)L.kept.size(), L.at.as<uint2>(), refs_d.as<Tri>());
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipStreamSynchronize(st));      // kept_d is reused by the next level
         }
-        words.push_back(((uint32_t)(uint16_t)n_tris << 16) | (mask << 8) | count);   // 16-bit count field (Octree.cpp:44)
-        words.push_back((uint32_t)n_ref);
-        n_ref += n_tris;
-        if (n_ref > 0xFFFFFFFFull) return rt_internal_set_error(RT_ELIMIT, "more than 2^32 triangle references");
-        const size_t first = words.size();
-        for (uint32_t i = 0; i < count; i++) words.push_back(0u);
-        size_t slot = first + count;
-        for (int o = 7; o >= 0; o--) if (mask & (1u << o)) stack.push_back({v.level + 1, L.kid[(size_t)v.node * 8 + o], --slot});
     }
-
     clock.lap(4);
+
     memset(out, 0, sizeof *out);
-    out->nodes = (uint32_t *)malloc(std::max<size_t>(1, words.size()) * 4);
-    out->tri_refs = (uint32_t *)malloc(std::max<size_t>(1, (size_t)n_ref) * 16);
-    if (!out->nodes || !out->tri_refs) { free(out->nodes); free(out->tri_refs); memset(out, 0, sizeof *out); return rt_internal_set_error(RT_ENOMEM, "out of memory"); }
+    out->nodes = (uint32_t *)malloc(std::max<size_t>(1, n_words) * 4);
+    out->tri_refs = (uint32_t *)malloc(std::max<size_t>(1, n_ref) * 16);
     auto fail_free = [&](int rc) { free(out->nodes); free(out->tri_refs); memset(out, 0, sizeof *out); return rc; };
-    if (n_ref) {
-        DevBuf refs_d, dest_d;
-        if (refs_d.alloc((size_t)n_ref * sizeof(Tri)) != hipSuccess) return fail_free(rt_internal_set_error(RT_ENOMEM, "out of device memory"));
-        for (size_t l = 0; l < levels.size(); l++) {
-            Level &L = *levels[l];
-            if (!L.n_pairs) continue;
-            if (dest_d.alloc((size_t)L.n_nodes * 4) != hipSuccess || !L.seg_d.p) return fail_free(rt_internal_set_error(RT_ENOMEM, "out of device memory"));
-            if (hipMemcpyAsync(dest_d.p, leaf_dest[l].data(), (size_t)L.n_nodes * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail_free(rt_internal_set_error(RT_ENODEVICE, "copy failed"));
-            emit_kernel<<<grid_for(L.n_pairs), BLOCK, 0, st>>>(L.pairs.as<Tri>(), L.node_of.as<uint32_t>(), L.seg_d.as<uint32_t>(), dest_d.as<uint32_t>(), L.n_pairs, refs_d.as<Tri>());
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail_free(rt_internal_set_error(RT_ENODEVICE, "emit kernel failed"));
-        }
-        if (hipMemcpyAsync(out->tri_refs, refs_d.p, (size_t)n_ref * sizeof(Tri), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-            return fail_free(rt_internal_set_error(RT_ENODEVICE, "copy of the reference list failed"));
-        for (const KeptCopy &k : kept_copies) {
-            const Level &L = *levels[k.level];
-            memcpy(out->tri_refs + 4 * (size_t)k.dest, L.kept.data() + L.kept_off[k.node], (size_t)(L.kept_off[k.node + 1] - L.kept_off[k.node]) * sizeof(Tri));
-        }
-    }
-    if (!words.empty()) memcpy(out->nodes, words.data(), words.size() * 4);
-    out->n_words = words.size(); out->n_ref = (size_t)n_ref; out->max_depth = max_depth;
+    if (!out->nodes || !out->tri_refs) return fail_free(rt_internal_set_error(RT_ENOMEM, "out of memory"));
+    if (hipMemcpyAsync(out->nodes, words_d.p, n_words * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (n_ref && hipMemcpyAsync(out->tri_refs, refs_d.p, n_ref * sizeof(Tri), hipMemcpyDeviceToHost, st) != hipSuccess) || hipStreamSynchronize(st) != hipSuccess)
+        return fail_free(rt_internal_set_error(RT_ENODEVICE, "copy of the flattened octree failed"));
+    out->n_words = n_words; out->n_ref = n_ref; out->max_depth = max_depth;
     for (int k = 0; k < 3; k++) { out->bounds_min[k] = root_lo[k]; out->bounds_max[k] = root_hi[k]; }
     clock.lap(5);
     clock.report();
