@@ -112,7 +112,7 @@ def main():
     t_build = time.time()
     scene_arrays = None
     if rank == 0:
-        oc = {"bunny": scenes.default_octree, "synthetic_100k": scenes.synthetic_100k, "synthetic_1m": scenes.synthetic_1m}[args.scene]()
+        oc = {"bunny": scenes.default_octree, "synthetic_100k": scenes.synthetic_100k, "synthetic_1m": scenes.synthetic_1m}[args.scene](device=local_rank)
         scene_arrays = oc.as_dict()
         scene_arrays["sky"] = scenes.procedural_skybox(900)
     if world > 1:

@@ -24,7 +24,8 @@ int main(int argc, char **argv) {
     fclose(in);
     try {
         rt::Mesh mesh(pos, {}, faces, 1, rt::mat4::scale(2.0f));
-        rt::Octree octree(std::vector<rt::Mesh>{mesh}, 18, 10, 6, 6);   // App.cpp:22
+        // App.cpp:22; with rendering (a GPU is there) the octree is built on the device, which gives the same arrays
+        rt::Octree octree(std::vector<rt::Mesh>{mesh}, 18, 10, 6, 6, argc == 7 ? 0 : -1);
         FILE *out = fopen(argv[2], "wb");
         if (!out) { perror(argv[2]); return 2; }
         const uint64_t sizes[3] = {octree.m_vertecies.size(), octree.m_compressed_triangles.size(), octree.m_compressed_node_buffer.size()};

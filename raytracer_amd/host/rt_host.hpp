@@ -66,7 +66,9 @@ private:
 
 class Octree {
 public:
-    Octree(const std::vector<Mesh> &meshes, size_t depth_limit, size_t max_triangles_per_node, size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps) {
+    // build_device < 0: the host builder; otherwise the construction runs on that GPU (identical arrays)
+    Octree(const std::vector<Mesh> &meshes, size_t depth_limit, size_t max_triangles_per_node, size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps,
+           int build_device = -1) {
         std::vector<rt_mesh> in(meshes.size());
         for (size_t i = 0; i < meshes.size(); i++) {
             const Mesh &m = meshes[i];
@@ -76,7 +78,8 @@ public:
             in[i].n_vert = m.m_vertecies.size(); in[i].n_tri = m.m_triangles.size();
         }
         rt_octree o{};
-        check(rt_octree_build(in.data(), in.size(), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, &o));
+        if (build_device < 0) check(rt_octree_build(in.data(), in.size(), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, &o));
+        else check(rt_octree_build_device(in.data(), in.size(), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, build_device, &o));
         m_vertecies.resize(o.n_vert); m_normals.resize(o.n_vert); m_compressed_triangles.resize(o.n_ref); m_compressed_node_buffer.resize(o.n_words);
         if (o.n_vert) { std::memcpy(m_vertecies.data(), o.vertices, o.n_vert * sizeof(vec4)); std::memcpy(m_normals.data(), o.normals, o.n_vert * sizeof(vec4)); }
         if (o.n_ref) std::memcpy(m_compressed_triangles.data(), o.tri_refs, o.n_ref * sizeof(uvec4));

@@ -24,9 +24,10 @@ def bunny_mesh(material_id: int = 1, scale: float = 20.0) -> api.Mesh:
     return api.Mesh(positions=z["positions"], faces=z["faces"], material_id=material_id, transform=api.scale_matrix(scale))
 
 
-def default_octree() -> api.Octree:
-    """Bunny stand-in of the reference's scene with the reference's octree parameters (App.cpp:22)."""
-    return api.Octree([bunny_mesh()], 18, 10, 6, 6)
+def default_octree(device: int | None = None) -> api.Octree:
+    """Bunny stand-in of the reference's scene with the reference's octree parameters (App.cpp:22).
+    device: GPU that runs the construction (None: the host builder); the arrays are the same either way."""
+    return api.Octree([bunny_mesh()], 18, 10, 6, 6, device=device)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -119,15 +120,15 @@ def synthetic_primitives(n_prims: int, *, seed: int = 1, sphere_subdiv: int = 0,
     return out_meshes
 
 
-def synthetic_100k() -> api.Octree:
+def synthetic_100k(device: int | None = None) -> api.Octree:
     """100 000 primitives (icospheres of 20 triangles and boxes of 12), seed 1, depth-8 octree: 1.6 M triangles."""
-    return api.Octree(synthetic_primitives(100_000, seed=1), 8, 10, 6, 6)
+    return api.Octree(synthetic_primitives(100_000, seed=1), 8, 10, 6, 6, device=device)
 
 
-def synthetic_1m() -> api.Octree:
+def synthetic_1m(device: int | None = None) -> api.Octree:
     """1 000 perturbed icospheres of 1 280 triangles each (seed 2), depth-18 octree: 1.28 M triangles."""
     meshes = synthetic_primitives(1000, seed=2, sphere_subdiv=3, extent=3.0, size_range=(0.15, 0.4), materials=(1, 5, 6, 2), perturb=0.01, boxes=False)
-    return api.Octree(meshes, 18, 10, 6, 6)
+    return api.Octree(meshes, 18, 10, 6, 6, device=device)
 
 
 def small_test_scene(seed: int = 3, n: int = 60) -> api.Octree:

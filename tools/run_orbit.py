@@ -50,7 +50,7 @@ def main():
 
     arrays = None
     if rank == 0:
-        arrays = {"bunny": scenes.default_octree, "synthetic_100k": scenes.synthetic_100k, "synthetic_1m": scenes.synthetic_1m}[args.scene]().as_dict()
+        arrays = {"bunny": scenes.default_octree, "synthetic_100k": scenes.synthetic_100k, "synthetic_1m": scenes.synthetic_1m}[args.scene](device=local_rank).as_dict()
         arrays["sky"] = scenes.procedural_skybox(900)
     if world > 1:
         arrays = rdist.broadcast_scene(arrays, device)
