@@ -102,7 +102,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 (with torch.distributed.run --nproc-per-node 1): the N > 1 code path -- RCCL process group,
+    # scene broadcast, pipelined gather -- with a single rank, to exercise the RCCL calls on a one-GPU box
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -115,7 +118,7 @@ def main():
         oc = {"bunny": scenes.default_octree, "synthetic_100k": scenes.synthetic_100k, "synthetic_1m": scenes.synthetic_1m}[args.scene](device=local_rank)
         scene_arrays = oc.as_dict()
         scene_arrays["sky"] = scenes.procedural_skybox(900)
-    if world > 1:
+    if use_dist:
         scene_arrays = rdist.broadcast_scene(scene_arrays, device)
     sky = scene_arrays["sky"]
     sc = api.Scene.from_dict(scene_arrays, device=local_rank)
@@ -148,11 +151,11 @@ def main():
     def render(step, accum_index, sync=False):
         sc.render_raw(frame_of(step, accum_index), target_of(sync))
 
-    gatherer = rdist.FrameGatherer(H, BAND_ROWS) if world > 1 else None
+    gatherer = rdist.FrameGatherer(H, BAND_ROWS) if use_dist else None
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -163,7 +166,7 @@ def main():
     present_every = max(1, args.present_every)
 
     def run_steps(frames):
-        chunk = len(frames) if world == 1 else present_every
+        chunk = len(frames) if not use_dist else present_every
         for first in range(0, len(frames), max(chunk, 1)):
             part = frames[first:first + chunk]
             if sequence:
@@ -171,9 +174,9 @@ def main():
             else:
                 for fr in part:
                     sc.render_raw(fr, target_of())
-            if world > 1:
+            if use_dist:
                 gatherer.submit(color)
-        if world > 1:
+        if use_dist:
             gatherer.last()
 
     # the per-frame inputs (camera matrices, time) are prepared before the clock starts: they are the caller's data
@@ -200,7 +203,7 @@ def main():
     elapsed = time.perf_counter() - t0
     k_total_ms, k_launches = sc.kernel_time()
     sc.set_kernel_timing(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -214,7 +217,7 @@ def main():
             tot[name] = tot.get(name, 0) + v
     sc.set_counting(False)
     local_tot = dict(tot)
-    if world > 1:
+    if use_dist:
         keys = sorted(tot)
         t = torch.tensor([tot[k] for k in keys], dtype=torch.int64, device=device)
         dist.all_reduce(t)
@@ -276,7 +279,7 @@ def main():
                                "sample": f"{n_frames} consecutive {W}x{H} frames of the same workload (time = k/60 s; {n_rays} rays) in {dt:.1f} s"}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
