@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: everything else that writes to file descriptor 1 (RCCL prints a version
+    # banner there when it starts) goes to stderr for the rest of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from raytracer_amd import api, scenes, dist as rdist
@@ -278,7 +284,7 @@ def main():
         out["cpu_baseline"] = {"value": round(n_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                                "sample": f"{n_frames} consecutive {W}x{H} frames of the same workload (time = k/60 s; {n_rays} rays) in {dt:.1f} s"}
     if rank == 0:
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--scene", default="bunny", choices=["bunny", "synthetic_100k", "synthetic_1m"])
     ap.add_argument("--checksum", action="store_true", help="rank 0 copies every presented frame to the host and prints its CRC32")
     args = ap.parse_args()
+    sys.stdout.flush()
+    result_fd = os.dup(1)      # stdout carries the one JSON line; RCCL's start-up banner and the like go to stderr
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -105,7 +108,7 @@ def main():
                "presentation": "bands gathered to rank 0 once per pose on a side stream" if world > 1 else "frame stays on the device"}
         if args.checksum:
             out["crc32_of_frames"] = sums
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
