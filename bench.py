@@ -53,8 +53,11 @@ def algorithmic_flops(st: dict) -> int:
     return 84 * 17 * st["rays"] + 27 * st["child_box_tests"] + 50 * st["triangle_tests"]
 
 
-def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this command, or None."""
+def measured_traffic(kernel: str, default_workload: bool):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this command, or None (the summary is
+    of the default single-GPU workload only)."""
+    if not default_workload:
+        return None
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
@@ -250,13 +253,14 @@ def main():
     if pipeline == "megakernel" and k_launches < args.steps:
         kernel = "render_batch_kernel"   # the library traced several frames of the sequence per launch
     k_ms = k_total_ms / max(k_launches, 1)
+    default_workload = world == 1 and args.scene == "bunny" and (W, H, args.max_recursion_limit) == (3840, 2160, 2)
     px_local = W * min(rows_local, H) if parts > 1 else W * H
     local_work = {k: v for k, v in local_tot.items()}
     total_bytes = traversal_bytes(local_work) if pipeline == "wavefront" else frame_bytes(local_work, px_local * args.steps, blended=True)
     abytes = total_bytes / max(k_launches, 1)
     achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     out["roofline"] = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(kernel), "kernel_ms": round(k_ms, 4),
+                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(kernel, default_workload), "kernel_ms": round(k_ms, 4),
                        "launches": k_launches, "algorithmic_bytes_per_launch": int(abytes),
                        "launches_per_frame": k_launches / args.steps, "frames_per_launch": args.steps / max(k_launches, 1),
                        "device_rate": {"what": "algorithmic bytes of this kernel per frame / frame time (its launches of one frame run concurrently on separate streams)",
