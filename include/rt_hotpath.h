@@ -177,7 +177,8 @@ int rt_scene_destroy(rt_scene *scene);
 
 /* Host-side scene build: mirrors of the reference's Mesh and Octree classes --------------------------------- */
 
-/* Mesh::Mesh (Mesh.cpp:11-101) on an OBJ file with triangle faces: positions transformed by the column-major
+/* Mesh::Mesh (Mesh.cpp:11-101) on an OBJ file with triangle or quad faces (quads are cut along the shorter diagonal, the
+ * rule of the OBJ library the reference reads files with; larger polygons are refused): positions transformed by the column-major
  * 4x4 `transform` with w = 0 (Mesh.cpp:44), normals from the file or accumulated face normals seeded with (1,0,0)
  * (Mesh.cpp:52,79-83,96-99), triangles (i0,i1,i2,material_id).  Outputs are malloc'ed; free with rt_mesh_free. */
 typedef struct rt_mesh {

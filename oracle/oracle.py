@@ -143,7 +143,11 @@ def _olib():
 
 
 def parse_obj(path: str):
-    """Minimal OBJ reader for the oracle: 'v', optional 'vn', triangle 'f' records (a, a/b, a//c, a/b/c forms)."""
+    """Minimal OBJ reader for the oracle: 'v', optional 'vn', 'f' records (a, a/b, a//c, a/b/c forms) with three or four
+    vertices.  The reference reads OBJ through tinyobjloader 2.0.0-rc10 with triangulation on (Mesh.cpp:12-14), a
+    dependency that is not part of the reference checkout: its rule for quads -- cut along the shorter diagonal, squared
+    lengths in float, (0,1,2)+(0,2,3) if |v0v2|^2 < |v1v3|^2 else (0,1,3)+(1,2,3) -- is restated from the published
+    source and is PARITY UNPINNED (no fixture of the reference covers it)."""
     pos, nrm, faces = [], [], []
     with open(path) as f:
         for line in f:
@@ -153,9 +157,19 @@ def parse_obj(path: str):
                 nrm.append([float(t) for t in line.split()[1:4]])
             elif line.startswith("f "):
                 idx = [int(t.split("/")[0]) for t in line.split()[1:]]
-                if len(idx) != 3:
-                    raise ValueError("only triangle faces are supported by the oracle reader")
-                faces.append([i - 1 if i > 0 else len(pos) + i for i in idx])
+                idx = [i - 1 if i > 0 else len(pos) + i for i in idx]
+                if len(idx) == 3:
+                    faces.append(idx)
+                elif len(idx) == 4:
+                    v = [np.asarray(pos[i], np.float64).astype(np.float32) for i in idx]
+                    e02, e13 = v[2] - v[0], v[3] - v[1]
+                    sqr02 = np.float32(np.float32(e02[0] * e02[0] + e02[1] * e02[1]) + e02[2] * e02[2])
+                    sqr13 = np.float32(np.float32(e13[0] * e13[0] + e13[1] * e13[1]) + e13[2] * e13[2])
+                    order = (0, 1, 2, 0, 2, 3) if sqr02 < sqr13 else (0, 1, 3, 1, 2, 3)
+                    faces.append([idx[k] for k in order[:3]])
+                    faces.append([idx[k] for k in order[3:]])
+                else:
+                    raise ValueError("faces with three or four vertices only")
     return (np.asarray(pos, np.float64).astype(np.float32), np.asarray(nrm, np.float64).astype(np.float32) if nrm else None,
             np.asarray(faces, np.uint32))
 

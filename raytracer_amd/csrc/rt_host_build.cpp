@@ -217,8 +217,21 @@ static int parse_obj(const char *path, ObjData &d, std::string &err) {
                 if (n < 4) { vi[n] = a; ni[n] = b; }
                 n++;
             }
-            if (n != 3) { fclose(f); err = "only triangle faces are supported"; return RT_ESCENE; }   // Mesh.cpp:60-63
-            for (int k = 0; k < 3; k++) { d.faces.push_back((uint32_t)vi[k]); d.face_normal_idx.push_back(ni[k]); }
+            // The reference reads OBJ files through tinyobjloader with triangulation on (Mesh.cpp:12-14,58-63), so what
+            // reaches it are triangles.  Triangles pass through; a quad is cut along its SHORTER diagonal, as that
+            // library's 2.0.0 release candidates do (squared lengths in float, (0,1,2)+(0,2,3) when |v0v2|^2 < |v1v3|^2,
+            // else (0,1,3)+(1,2,3)); larger polygons (its ear clipping) are not restated and are refused.
+            if (n < 3 || n > 4) { fclose(f); err = n < 3 ? "face with fewer than three vertices" : "faces with more than four vertices are not supported"; return RT_ESCENE; }
+            int order[6] = {0, 1, 2, 0, 2, 3};
+            if (n == 4) {
+                for (int k = 0; k < 4; k++)
+                    if (vi[k] < 0 || (size_t)vi[k] >= d.pos.size() / 3) { fclose(f); err = "face indexes a vertex that does not exist"; return RT_ESCENE; }
+                const float *v0 = &d.pos[3 * (size_t)vi[0]], *v1 = &d.pos[3 * (size_t)vi[1]], *v2 = &d.pos[3 * (size_t)vi[2]], *v3 = &d.pos[3 * (size_t)vi[3]];
+                const float e02[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]}, e13[3] = {v3[0] - v1[0], v3[1] - v1[1], v3[2] - v1[2]};
+                const float sqr02 = e02[0] * e02[0] + e02[1] * e02[1] + e02[2] * e02[2], sqr13 = e13[0] * e13[0] + e13[1] * e13[1] + e13[2] * e13[2];
+                if (!(sqr02 < sqr13)) { const int alt[6] = {0, 1, 3, 1, 2, 3}; for (int k = 0; k < 6; k++) order[k] = alt[k]; }
+            }
+            for (int k = 0; k < (n == 4 ? 6 : 3); k++) { d.faces.push_back((uint32_t)vi[order[k]]); d.face_normal_idx.push_back(ni[order[k]]); }
         }
     }
     fclose(f);

@@ -124,11 +124,21 @@ def test_obj_reader(tmp_path):
     tri.write_text("# c\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\nf 1//1 3//3 4//4\nf -4 -3 -1\n")
     m = api.Mesh(str(tri), 4)
     assert m.m_triangles.tolist() == [[0, 1, 2, 4], [0, 2, 3, 4], [0, 1, 3, 4]]
+    # quads: cut along the shorter diagonal (the rule of the OBJ library the reference links, which is not part of the
+    # reference checkout: PARITY UNPINNED); larger polygons are refused
     quad = tmp_path / "q.obj"
-    quad.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
-    with pytest.raises(api.RtError) as e:      # Mesh.cpp:60-63: only triangle faces
-        api.Mesh(str(quad), 0)
-    assert e.value.code == api.RT_ESCENE and "triangle" in str(e.value)
+    quad.write_text("v 0 0 0\nv 1 0 0\nv 3 1 0\nv 0 1 0\n"      # |v0v2|^2 = 10 > |v1v3|^2 = 2  -> (0,1,3) (1,2,3)
+                    "v 0 0 1\nv 3 0 1\nv 1 1 1\nv 0 1 1\n"      # |v0v2|^2 = 2 < |v1v3|^2 = 10  -> (0,1,2) (0,2,3)
+                    "v 0 0 2\nv 1 0 2\nv 1 1 2\nv 0 1 2\n"      # equal diagonals               -> (0,1,3) (1,2,3)
+                    "f 1 2 3 4\nf 5 6 7 8\nf 9//9 10//10 11//11 12//12\nf 1 2 3\n")
+    q = api.Mesh(str(quad), 2)
+    assert q.m_triangles[:, :3].tolist() == [[0, 1, 3], [1, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 11], [9, 10, 11], [0, 1, 2]]
+    assert np.array_equal(oracle.parse_obj(str(quad))[2], q.m_triangles[:, :3])
+    penta = tmp_path / "p.obj"
+    penta.write_text("v 0 0 0\nv 1 0 0\nv 2 1 0\nv 1 2 0\nv 0 1 0\nf 1 2 3 4 5\n")
+    with pytest.raises(api.RtError) as e:
+        api.Mesh(str(penta), 0)
+    assert e.value.code == api.RT_ESCENE and "four" in str(e.value)
     with pytest.raises(api.RtError):
         api.Mesh(str(tmp_path / "missing.obj"), 0)
     bad = tmp_path / "n.obj"
