@@ -520,7 +520,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     // at 8K are 0.2 s): a long sequence is issued as a short probe part, which the selection may use to try a pipeline,
     // and the rest, which always runs on the best one known.
     const size_t probe_frames = (size_t)f->width * f->height >= ((size_t)1 << 23) ? 4 : 8;
-    if (s->pipeline == RT_PIPELINE_AUTO && !s->tuner.in_split && !s->counting && t->memory == RT_MEM_DEVICE && n_frames > 2 * probe_frames) {
+    if (s->pipeline == RT_PIPELINE_AUTO && !s->tuner.in_split && !s->counting && t->memory == RT_MEM_DEVICE && n_frames > probe_frames) {
         rt_target head = *t;
         head.sync = 0;
         s->tuner.in_split = true;
