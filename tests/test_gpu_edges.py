@@ -137,3 +137,25 @@ def test_malformed_node_buffers_are_rejected():
     with pytest.raises(api.RtError) as e:
         create(good, tri_refs=bad_refs)
     assert e.value.code == api.RT_ESCENE
+
+
+def test_triangle_count_beyond_16_bits_wraps_like_the_node_word(bunny_octree, test_sky):
+    """A node's triangle count lives in 16 bits of its header word (Octree.cpp:44, frag:460): with depth_limit 1 the root
+    is a leaf holding all 69 451 bunny triangles, the word keeps 69 451 mod 65 536 = 3 915, and the shader tests only
+    those.  Host builder, device builder, kernels and oracle must all do the same."""
+    from oracle import oracle
+    mesh = [scenes.bunny_mesh()]
+    oc = api.Octree(mesh, 1, 10, 6, 6)
+    dev = api.Octree(mesh, 1, 10, 6, 6, device=0)
+    n_tri = len(oc.m_compressed_triangles)
+    assert n_tri > 65535 and int(oc.m_compressed_node_buffer[0]) >> 16 == n_tri % 65536 and len(oc.m_compressed_node_buffer) == 2
+    assert np.array_equal(oc.m_compressed_node_buffer, dev.m_compressed_node_buffer) and np.array_equal(oc.m_compressed_triangles, dev.m_compressed_triangles)
+    sc = api.Scene.from_octree(oc)
+    sc.set_skybox(test_sky)
+    u = Uniforms.from_camera(Camera(aspect=1.0), max_recursion_limit=3).pack()
+    o = oracle.OracleScene(oc.as_dict(), test_sky).render(u, 48, 48)
+    assert (o["kind"] == api.HIT_TRIANGLE).any()
+    for pipe in PIPELINES:
+        sc.set_pipeline(pipe)
+        same(o, sc.render(u, 48, 48), pipe)
+    sc.close()
