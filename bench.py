@@ -12,9 +12,10 @@ App::Render does (time advances by 1/60 s per frame).  One step = one frame.  Me
 FindIntersection call (path segment); rays are COUNTED by replaying the timed frames with the library's work counters on.
 
 N > 1: the frame is sharded by interleaved 16-row strips over the ranks (strong scaling), the scene is broadcast from
-rank 0, every rank accumulates its own bands, and the accumulated frame is gathered to rank 0 with RCCL after every 16
-steps inside the timed region (on a side stream while rendering goes on; the last gather is waited for before the clock
-stops).  A 4K RGBA32F frame is 132.7 MB: gathered after every 0.1 ms step it would measure the xGMI links.
+rank 0, every rank accumulates its own bands, and the accumulated frame is gathered to rank 0 with RCCL after every 16 x N
+steps -- about 100 presentations per second whatever N is -- and after the last step, inside the timed region (on a side
+stream while rendering goes on; the last gather is waited for before the clock stops).  A 4K RGBA32F frame is 132.7 MB:
+gathered after every 0.1 ms step it would measure the xGMI links.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -78,9 +79,10 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront", "megakernel"])
     ap.add_argument("--subframes", type=int, default=None)
     ap.add_argument("--per-frame-calls", action="store_true", help="one rt_render per step instead of rt_render_sequence calls")
-    ap.add_argument("--present-every", type=int, default=16,
-                    help="N > 1: the accumulated frame is gathered to rank 0 after every this many steps (a 4K RGBA32F frame is 132.7 MB: "
-                         "gathering it after every 0.1 ms step would measure the xGMI links, not the renderer)")
+    ap.add_argument("--present-every", type=int, default=0,
+                    help="N > 1: the accumulated frame is gathered to rank 0 after every this many steps and after the last one. "
+                         "0 = 16 x N: a step takes about 0.67 ms / N, so the frame is presented about 100 times a second whatever N is "
+                         "(a 4K RGBA32F frame is 132.7 MB: gathered after every step it would measure the xGMI links, not the renderer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -172,7 +174,7 @@ def main():
     # On several GPUs every rank accumulates its own bands; the accumulated frame is presented -- its bands gathered to
     # rank 0 on a side stream while rendering goes on -- after every `present_every` steps and after the last one.
     sequence = not args.per_frame_calls
-    present_every = max(1, args.present_every)
+    present_every = args.present_every if args.present_every > 0 else 16 * max(world, 1)
 
     def run_steps(frames):
         chunk = len(frames) if not use_dist else present_every
@@ -241,7 +243,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": ("REHEARSAL on one GPU, not a measurement; " if rehearse else "") + "synthetic camera/skybox; bundled bunny mesh (default scene's dragon is absent from the reference checkout)",
         "config": {"workload": f"{args.scene} default-style scene {W}x{H}, max_recursion_limit={args.max_recursion_limit} (primary + one secondary segment), 1 spp/frame, progressive accumulation",
                    "width": W, "height": H, "max_recursion_limit": args.max_recursion_limit, "band_rows": BAND_ROWS,
-                   "parallelism": f"interleaved row bands x{world}" + (f" + RCCL gather of the accumulated frame every {max(1, args.present_every)} steps" if world > 1 else "")},
+                   "parallelism": f"interleaved row bands x{world}" + (f" + RCCL gather of the accumulated frame every {present_every} steps (about 100 presentations per second) and after the last step" if world > 1 else "")},
         "rays_per_frame": rays / args.steps, "rays_per_pixel": rays / args.steps / (W * H),
         "work_per_frame": {k: v / args.steps for k, v in tot.items()},
         "scene_build_s": round(t_build, 3),
