@@ -648,7 +648,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
                     i++;
                     continue;
                 }
-                if (s->stage_elems < nb * px) {
+                if (rt_batch_groups((uint32_t)nb) > 1u && s->stage_elems < nb * px) {
                     if (s->stage) { if (hipDeviceSynchronize() != hipSuccess) return 1; (void)hipFree(s->stage); s->stage = nullptr; s->stage_elems = 0; }
                     if (hipMalloc(&s->stage, batch * px * 16) != hipSuccess) return 1;
                     s->stage_elems = batch * px;

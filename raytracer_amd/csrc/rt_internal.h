@@ -90,6 +90,10 @@ struct RtWorkspace {
 // the samples of each pixel in frame order.  With that a launch keeps the machine busy even when its share of the frame
 // is small (one of 8 ranks' bands), instead of ending on the serial chain of its single longest path n times over.
 #define RT_MAX_BATCH 8
+// The batched kernel runs one wave per frame: RT_BATCH_BLOCK / 64 frames of an 8x8 pixel tile share a workgroup.  A batch
+// that fits one such group is blended inside the kernel; a larger one goes through the staging plane and blend_batch_kernel.
+#define RT_BATCH_BLOCK 256
+static inline uint32_t rt_batch_groups(uint32_t n_frames) { return (n_frames + RT_BATCH_BLOCK / 64u - 1u) / (RT_BATCH_BLOCK / 64u); }
 struct RtBatch {
     rt_uniforms u[RT_MAX_BATCH];
     uint32_t accum_index[RT_MAX_BATCH], blend[RT_MAX_BATCH];

@@ -947,7 +947,11 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
     __shared__ PortalBasis lds_portals_all[BATCH ? 2u * WAVES : 2u];
     // BATCH: the waves of a workgroup render the SAME 8x8 pixels for different frames of the batch.  Their primary rays
     // differ only by the sub-pixel jitter, so they walk the same nodes and triangles at the same time and share the
-    // CU's vector cache.  Workgroup b: frames (b % groups) * WAVES + wave, 8x8 tile b / groups of the cost-ordered list.
+    // CU's vector cache.  Workgroup b: frames (b % groups) * WAVES + wave, 8x8 tile b / groups of the cost-ordered list
+    // (a unit of that list is UNIT_TILES such tiles, whatever the workgroup size).  When one workgroup holds all frames
+    // of the batch (groups == 1) it also blends them into the target, in frame order, through LDS; otherwise the samples
+    // are staged for blend_batch_kernel.
+    constexpr uint32_t UNIT_TILES = RENDER_BLOCK / 64u;
     const uint32_t groups = BATCH ? (B->n + WAVES - 1u) / WAVES : 1u;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t frame_raw = BATCH ? (blockIdx.x % groups) * WAVES + wave : 0u;
@@ -975,12 +979,15 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
     // With a cost order from the previous frame of the same view (L.order) the most expensive units start first.
     const unsigned long long t_start = L.cost ? wall_clock64() : 0ull;
     const uint32_t q = BATCH ? blockIdx.x / groups : 0u;                       // BATCH: 8x8 tile index in the ordered list
-    const uint32_t slot = BATCH ? q / WAVES : blockIdx.x;
+    const uint32_t slot = BATCH ? q / UNIT_TILES : blockIdx.x;
     const uint32_t unit = L.order ? L.order[slot] : slot;
     uint32_t tile_x, tile_y;
-    path_tile(L, unit / (256u / BLOCK), tile_x, tile_y);
-    PixelId p = pixel_of_tile(L, tile_x, tile_y, (unit % (256u / BLOCK)) * BLOCK + (BATCH ? (q % WAVES) * 64u + lane : threadIdx.x));
+    path_tile(L, unit / (256u / RENDER_BLOCK), tile_x, tile_y);
+    PixelId p = pixel_of_tile(L, tile_x, tile_y, (unit % (256u / RENDER_BLOCK)) * RENDER_BLOCK + (BATCH ? (q % UNIT_TILES) * 64u + lane : threadIdx.x));
+    const bool in_frame = p.active;
     p.active = p.active && frame_ok;
+    const bool fused_blend = BATCH && groups == 1u;
+    f3 out = F3(0.0f, 0.0f, 0.0f);
     Counters cn = {0, 0, 0, 0, 0, 0};
     if (p.active) {
         float nx, ny;
@@ -1027,12 +1034,26 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
             scatter(U, h, ray, color, seed);
             ray.inv = rcp3(ray.dir);
         }
-        const f3 out = tonemap(color);
-        if (BATCH) B->stage[(size_t)frame * B->stage_stride + (size_t)p.lr * L.width + p.x] = make_float4(out.x, out.y, out.z, 0.0f);
-        else write_pixel(L, p.pi, out);
+        out = tonemap(color);
+        if (!BATCH) write_pixel(L, p.pi, out);
+        else if (!fused_blend) B->stage[(size_t)frame * B->stage_stride + (size_t)p.lr * L.width + p.x] = make_float4(out.x, out.y, out.z, 0.0f);
         if (L.n_rays && (!BATCH || frame + 1u == B->n)) L.n_rays[p.pi] = nrays;
     }
     if (L.cost && (threadIdx.x & 63u) == 0) atomicMax(&L.cost[unit], (uint32_t)min(wall_clock64() - t_start, 0xFFFFFFFFull) + 1u);
+    if (fused_blend) {
+        // the traversal stacks are dead once every wave is here: their LDS carries the samples to the first wave, which
+        // applies them to its 64 pixels frame after frame (App.cpp:49,102-105)
+        __syncthreads();
+        f3 *samples = reinterpret_cast<f3 *>(lds_stack);
+        samples[threadIdx.x] = out;
+        __syncthreads();
+        if (wave == 0 && in_frame) {
+            float4 *dstp = reinterpret_cast<float4 *>(L.color) + p.pi;
+            float4 dst = *dstp;
+            for (uint32_t f = 0; f < B->n; f++) dst = blend_sample(dst, samples[f * 64u + lane], B->accum_index[f], B->blend[f]);
+            *dstp = dst;
+        }
+    }
     if (COUNT && L.counters) flush_counters(L.counters, cn);
 }
 
@@ -1521,10 +1542,10 @@ template <int LEVELS>
 int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid, const RtBatch *batch) {
     grid.x *= 256u / RENDER_BLOCK;
     if (batch) {
-        constexpr uint32_t WAVES = RENDER_BLOCK / 64u;
-        grid.x *= WAVES * ((batch->n + WAVES - 1u) / WAVES);   // one workgroup per 8x8 tile and group of WAVES frames
-        if (L.counters) hipLaunchKernelGGL((render_batch_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
-        else hipLaunchKernelGGL((render_batch_kernel<LEVELS, false, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L, *batch);
+        // one workgroup per 8x8 tile and group of RT_BATCH_BLOCK / 64 frames
+        grid.x *= (RENDER_BLOCK / 64u) * rt_batch_groups(batch->n);
+        if (L.counters) hipLaunchKernelGGL((render_batch_kernel<LEVELS, true, RT_BATCH_BLOCK>), grid, dim3(RT_BATCH_BLOCK), 0, st, S, L, *batch);
+        else hipLaunchKernelGGL((render_batch_kernel<LEVELS, false, RT_BATCH_BLOCK>), grid, dim3(RT_BATCH_BLOCK), 0, st, S, L, *batch);
         return (int)hipGetLastError();
     }
     if (L.counters) hipLaunchKernelGGL((render_kernel<LEVELS, true, RENDER_BLOCK>), grid, dim3(RENDER_BLOCK), 0, st, S, L);
@@ -1588,7 +1609,7 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         else if (need <= 20) rc = launch_megakernel<20>(S, L, st, grid, batch);
         else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid, batch);
         mark(1);
-        if (batch) hipLaunchKernelGGL(blend_batch_kernel, dim3((L.width * L.n_local_rows + 255u) / 256u), dim3(256), 0, st, L, *batch);
+        if (batch && rt_batch_groups(batch->n) > 1u) hipLaunchKernelGGL(blend_batch_kernel, dim3((L.width * L.n_local_rows + 255u) / 256u), dim3(256), 0, st, L, *batch);
         if (L.cost && L.order_next) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, L.cost, L.order_next, n_tiles * (256u / RENDER_BLOCK));
         if (timed) probe->launches[probe->used++] = 1;
     } else {
