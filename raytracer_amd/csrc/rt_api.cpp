@@ -401,8 +401,12 @@ int rt_scene_set_counting(rt_scene *s, int enabled) {
     return RT_OK;
 }
 
-#ifndef RT_BATCH_SHIFT
-#define RT_BATCH_SHIFT 25   // a batch covers up to about 2^25 pixels (four 4K frames; measured 4 % faster than one)
+// Frames per batched launch (see RtBatch).  RT_BATCH_BLOCK / 64 = 4 frames are blended inside the kernel and need no staging
+// plane, so that is the batch whenever four frames' worth of this launch's pixels fill the machine; below
+// RT_FUSED_MIN_PIXELS pixels per frame (measured: one of 8 ranks' share of a 4K frame, 1.04 M pixels, 0.087 ms per frame
+// in fours and 0.078 in eights; one of 4 ranks' share, 2.07 M, 0.150 against 0.153) RT_MAX_BATCH frames go through staging.
+#ifndef RT_FUSED_MIN_PIXELS
+#define RT_FUSED_MIN_PIXELS (((size_t)1 << 20) + ((size_t)1 << 19))
 #endif
 #define RT_PROBE_PAIRS 4096u
 int rt_scene_set_kernel_timing(rt_scene *s, int enabled) {
@@ -636,7 +640,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             // keep the machine busy and still lasts as long as its longest path, so consecutive frames of a sequence are
             // traced together: `batch` frames per launch (see RtBatch).
             const size_t px = (size_t)f->width * L0.n_local_rows;
-            size_t batch = px ? std::min<size_t>(RT_MAX_BATCH, ((size_t)1 << RT_BATCH_SHIFT) / px) : 1;
+            size_t batch = px >= RT_FUSED_MIN_PIXELS ? RT_BATCH_BLOCK / 64u : RT_MAX_BATCH;
             if (s->max_batch > 0) batch = std::min<size_t>(batch, (size_t)s->max_batch);
             for (size_t i = 0; i < n_frames;) {
                 const size_t nb = std::min(batch, n_frames - i);

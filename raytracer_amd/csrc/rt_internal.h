@@ -92,7 +92,9 @@ struct RtWorkspace {
 #define RT_MAX_BATCH 8
 // The batched kernel runs one wave per frame: RT_BATCH_BLOCK / 64 frames of an 8x8 pixel tile share a workgroup.  A batch
 // that fits one such group is blended inside the kernel; a larger one goes through the staging plane and blend_batch_kernel.
+#ifndef RT_BATCH_BLOCK
 #define RT_BATCH_BLOCK 256
+#endif
 static inline uint32_t rt_batch_groups(uint32_t n_frames) { return (n_frames + RT_BATCH_BLOCK / 64u - 1u) / (RT_BATCH_BLOCK / 64u); }
 struct RtBatch {
     rt_uniforms u[RT_MAX_BATCH];

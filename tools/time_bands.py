@@ -9,7 +9,9 @@ from raytracer_amd import api, scenes, dist as rdist
 from raytracer_amd.camera import Camera
 from raytracer_amd.params import Uniforms
 W, H = 3840, 2160
+MAX_BATCH = int(os.environ.get("RT_TIME_BANDS_BATCH", "0"))      # 0: the library's choice
 sc = api.Scene.from_dict(scenes.default_octree().as_dict()); sc.set_skybox(scenes.procedural_skybox(900))
+sc.set_sequence_batch(MAX_BATCH)
 for parts in (1, 2, 4, 8):
     rows = rdist.padded_row_count(H, 16, parts) if parts > 1 else H
     color = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
