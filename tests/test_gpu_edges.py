@@ -159,3 +159,31 @@ def test_triangle_count_beyond_16_bits_wraps_like_the_node_word(bunny_octree, te
         sc.set_pipeline(pipe)
         same(o, sc.render(u, 48, 48), pipe)
     sc.close()
+
+
+def test_scene_lifecycle_returns_its_device_memory(bunny_octree, test_sky):
+    """Create / render with every pipeline / render a batched sequence / destroy, repeatedly: the free device memory
+    after the third round equals that after the tenth (workspaces, staging planes, cost maps, events all go with the scene)."""
+    import torch
+    u = Uniforms.from_camera(Camera(aspect=16 / 9), max_recursion_limit=3).pack()
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    base = None
+    for it in range(10):
+        sc = api.Scene.from_octree(bunny_octree, device=0)
+        sc.set_skybox(test_sky)
+        for pipe in PIPELINES + ["auto"]:
+            sc.set_pipeline(pipe)
+            sc.render(u, 320, 180, planes=False)
+        color = torch.zeros((180, 320, 4), device="cuda")
+        tg = api.rt_target()
+        tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 1, color.data_ptr()
+        sc.render_sequence_raw([api.make_frame(u, 320, 180, accum_index=k + 1) for k in range(12)], tg)
+        sc.close()
+        api.Octree([scenes.bunny_mesh()], 5, 10, 6, 6, device=0)
+        if it == 2:
+            base = free_bytes()
+    assert abs(base - free_bytes()) < (32 << 20)
