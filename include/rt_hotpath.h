@@ -210,7 +210,7 @@ int rt_octree_build(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, 
                     size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, rt_octree *out);
 /* The same construction with Subdivide's triangle/box overlap tests and the distribution of the triangle references to
  * the children (Octree.cpp:146-170,182-192; TriangleBoxIntersection.hpp:153-240) run on HIP device `device`, level by
- * level; the "keep" selection (Octree.cpp:172-181) and the flattening (Octree.cpp:38-85) stay on the host.  Output
+ * level; only the "keep" selection (Octree.cpp:172-181), a library sort of a few records per node, stays on the host.  Output
  * arrays are host memory, bit-identical to rt_octree_build's.  Fails with RT_ENODEVICE without a GPU. */
 int rt_octree_build_device(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, size_t max_triangles_per_node,
                            size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, int device,

@@ -2,13 +2,13 @@
 // the render entry point.  Replaces the GL resource handling around the reference's render pass
 // (app/core/src/App.cpp:23-26,96-140, Buffer.cpp:3-14, Skybox.cpp:46-57, Framebuffer.cpp:6-12).
 #include <hip/hip_runtime_api.h>
-#include <xmmintrin.h>
-#include <pmmintrin.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -35,13 +35,6 @@ int fail(int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-
-// The shader flushes denormals; the host-side precomputation of boxes and edges must do the same.
-struct FlushDenormals {
-    unsigned saved;
-    FlushDenormals() : saved(_mm_getcsr()) { _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON); }
-    ~FlushDenormals() { _mm_setcsr(saved); }
-};
 
 }  // namespace
 
@@ -106,63 +99,6 @@ void free_staging(rt_scene *s) {
     void **p[] = {&s->s_color, &s->s_depth, &s->s_kind, &s->s_slot, &s->s_t, &s->s_nrays, &s->s_ndcx, &s->s_ndcy};
     for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
     s->s_pixels = 0;
-}
-
-// Walks the reference node words (Octree.cpp:44-75; read by the shader at frag:460-464,481-484) breadth-first from
-// the root, checks every offset the shader would dereference, and emits one 64-byte record per visited node.
-int flatten_nodes(const uint32_t *words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3],
-                  std::vector<RtNodeRec> &out, uint32_t &max_depth) {
-    out.clear();
-    max_depth = 0;
-    if (n_words == 0) return RT_OK;
-    if (n_words < 2) return fail(RT_ESCENE, "node buffer has %zu words; a node needs at least 2", n_words);
-    struct Item { uint32_t word, depth; };
-    const uint32_t HOLE = 0xFFFFFFFFu;
-    std::vector<Item> items;        // items[i] describes out[i]; processed in order = breadth-first
-    const size_t max_nodes = n_words;     // a tree cannot hold more nodes than words
-    size_t n_nodes = 0;
-    auto add = [&](uint32_t word, uint32_t depth, const float lo[3], const float hi[3]) {
-        RtNodeRec r{};
-        for (int k = 0; k < 3; k++) { r.lo[k] = lo[k]; r.hi[k] = hi[k]; r.mid[k] = (hi[k] + lo[k]) / 2.0f; }   // frag:487
-        out.push_back(r);
-        items.push_back({word, depth});
-        n_nodes++;
-    };
-    add(0u, 0u, lo0, hi0);
-    for (size_t i = 0; i < out.size(); i++) {
-        const Item it = items[i];
-        if (it.word == HOLE) continue;
-        if ((size_t)it.word + 2 > n_words) return fail(RT_ESCENE, "node at word %u runs past the node buffer (%zu words)", it.word, n_words);
-        const uint32_t info = words[it.word], tri_start = words[it.word + 1];
-        const uint32_t child_count = info & 0xFu, mask = (info >> 8) & 0xFFu, tri_count = info >> 16;
-        if ((uint32_t)__builtin_popcount(mask) != child_count) return fail(RT_ESCENE, "node at word %u: child count %u does not match child mask 0x%02x", it.word, child_count, mask);
-        if ((info & 0xF0u) != 0) return fail(RT_ESCENE, "node at word %u: child count field has bits above 0xF set", it.word);
-        if ((size_t)it.word + 2 + child_count > n_words) return fail(RT_ESCENE, "node at word %u: child pointers run past the node buffer", it.word);
-        if ((size_t)tri_start + tri_count > n_ref) return fail(RT_ESCENE, "node at word %u: triangle range [%u,%u) exceeds %zu references", it.word, tri_start, tri_start + tri_count, n_ref);
-        if (it.depth > max_depth) max_depth = it.depth;
-        if (child_count && it.depth + 1 > RT_MAX_TREE_DEPTH) return fail(RT_ESCENE, "octree deeper than %u levels (or cyclic)", RT_MAX_TREE_DEPTH);
-        if (n_nodes + child_count > max_nodes) return fail(RT_ESCENE, "node buffer describes more than %zu nodes (shared or cyclic children)", max_nodes);
-        if (child_count && out.size() + 8 > RT_MAX_NODE_RECORDS) return fail(RT_ELIMIT, "octree needs more than %u node records", RT_MAX_NODE_RECORDS);
-        float lo[3], hi[3], mid[3];
-        for (int k = 0; k < 3; k++) { lo[k] = out[i].lo[k]; hi[k] = out[i].hi[k]; mid[k] = out[i].mid[k]; }
-        out[i].info = info;
-        out[i].tri_start = tri_start;
-        out[i].first_child = (uint32_t)out.size();
-        uint32_t ci = 0;
-        for (int o = 0; o < 8 && child_count; o++) {
-            if (!(mask & (1u << o))) { out.push_back(RtNodeRec{}); items.push_back({HOLE, 0u}); continue; }   // slot of a child that does not exist
-            const uint32_t cw = words[it.word + 2 + ci++];
-            float clo[3], chi[3];
-            for (int k = 0; k < 3; k++) {   // frag:491-500
-                const bool upper = (o >> k) & 1;
-                clo[k] = upper ? mid[k] : lo[k];
-                chi[k] = upper ? hi[k] : mid[k];
-            }
-            add(cw, it.depth + 1, clo, chi);
-        }
-    }
-    if (out.size() > RT_MAX_NODE_RECORDS) return fail(RT_ELIMIT, "octree has %zu nodes; at most %u are supported", out.size(), RT_MAX_NODE_RECORDS);
-    return RT_OK;
 }
 
 // Frame-space pixel rectangle (x0, y0, x1, y1 inclusive) that the scene's octree bounds project to under the frame's
@@ -284,37 +220,19 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     if (!bounds_min || !bounds_max) return fail(RT_EINVAL, "bounds are null");
     if ((n_vert && (!vertices || !normals)) || (n_ref && !tri_refs) || (n_words && !nodes)) return fail(RT_EINVAL, "null array with non-zero size");
     if (n_vert > 0xFFFFFFFFull || n_ref > 0xFFFFFFFFull || n_words > 0xFFFFFFFFull) return fail(RT_ELIMIT, "array sizes must fit 32 bits");
+    // RT_BUILD_TRACE=1: wall time of the phases on stderr
+    const bool trace = getenv("RT_BUILD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_phase = now();
+    double t_check = 0.0, t_flatten = 0.0, t_upload = 0.0;
     for (size_t i = 0; i < n_ref; i++) {
         const uint32_t *t = tri_refs + 4 * i;
         if (t[0] >= n_vert || t[1] >= n_vert || t[2] >= n_vert) return fail(RT_ESCENE, "triangle reference %zu indexes vertex >= %zu", i, n_vert);
         if (t[3] >= RT_NUM_MATERIALS) return fail(RT_ESCENE, "triangle reference %zu has material id %u >= %u", i, t[3], RT_NUM_MATERIALS);
     }
-    std::vector<RtNodeRec> recs;
-    std::vector<RtTriRec> tris(n_ref);
-    uint32_t max_depth = 0;
-    {
-        FlushDenormals ftz;
-        int rc = flatten_nodes(nodes, n_words, n_ref, bounds_min, bounds_max, recs, max_depth);
-        if (rc != RT_OK) return rc;
-        for (size_t i = 0; i < n_ref; i++) {   // frag:469-471,256-257
-            const uint32_t *t = tri_refs + 4 * i;
-            const float *a = vertices + 4 * (size_t)t[0], *b = vertices + 4 * (size_t)t[1], *c = vertices + 4 * (size_t)t[2];
-            RtTriRec &r = tris[i];
-            r.v1[0] = a[0]; r.v1[1] = a[1]; r.v1[2] = a[2];
-            r.e1x = b[0] - a[0]; r.e1y = b[1] - a[1]; r.e1z = b[2] - a[2];
-            r.e2x = c[0] - a[0]; r.e2y = c[1] - a[1]; r.e2z = c[2] - a[2];
-            r.pad[0] = r.pad[1] = r.pad[2] = 0;
-        }
-        // A leaf has no child boxes to derive, so its box fields carry its first triangle record instead (nine floats
-        // either way): visiting a leaf with one triangle then takes one memory round trip, not two.
-        for (RtNodeRec &n : recs) {
-            if ((n.info & 0xFu) != 0u || (n.info >> 16) == 0u) continue;
-            const RtTriRec &r = tris[n.tri_start];
-            n.lo[0] = r.v1[0]; n.lo[1] = r.v1[1]; n.lo[2] = r.v1[2];
-            n.mid[0] = r.e1x; n.mid[1] = r.e1y; n.mid[2] = r.e1z;
-            n.hi[0] = r.e2x; n.hi[1] = r.e2y; n.hi[2] = r.e2z;
-        }
-    }
+    t_check = ms_since(t_phase); t_phase = now();
+    if (n_words == 1) return fail(RT_ESCENE, "node buffer has 1 word; a node needs at least 2");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -327,11 +245,38 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     DeviceGuard guard(dev);
     if (!guard.ok) { delete s; return fail(RT_ENODEVICE, "cannot select HIP device %d", dev); }
     int rc = RT_OK;
+    void *d_words = nullptr;
     if ((rc = upload(&s->d_vertices, vertices, n_vert * 16)) || (rc = upload(&s->d_normals, normals, n_vert * 16)) ||
-        (rc = upload(&s->d_refs, tri_refs, n_ref * 16)) || (rc = upload(&s->d_nodes, recs.data(), recs.size() * sizeof(RtNodeRec))) ||
-        (rc = upload(&s->d_tris, tris.data(), tris.size() * sizeof(RtTriRec)))) {
+        (rc = upload(&s->d_refs, tri_refs, n_ref * 16)) || (rc = upload(&d_words, nodes, n_words * 4))) {
         rt_scene_destroy(s);
         return rc;
+    }
+    t_upload = ms_since(t_phase); t_phase = now();
+    // Everything the kernels traverse is derived from those arrays on the device: the node records (the words walked
+    // breadth-first and checked, Octree.cpp:44-75 / frag:460-500), the triangle records and the leaves' inline triangles.
+    RtNodeBuild nb{};
+    rc = rt_build_node_records((const uint32_t *)d_words, n_words, n_ref, bounds_min, bounds_max, &nb);
+    if (d_words) (void)hipFree(d_words);
+    if (rc != RT_OK) {
+        rt_scene_destroy(s);
+        switch (nb.error) {
+        case 1: return fail(rc, "node at word %u runs past the node buffer (%zu words)", nb.error_word, n_words);
+        case 2: return fail(rc, "node at word %u: child count does not match its child mask", nb.error_word);
+        case 3: return fail(rc, "node at word %u: child count field has bits above 0xF set", nb.error_word);
+        case 4: return fail(rc, "node at word %u: child pointers run past the node buffer", nb.error_word);
+        case 5: return fail(rc, "node at word %u: triangle range exceeds the %zu references", nb.error_word, n_ref);
+        case RT_NODE_ERROR_TOO_DEEP: return fail(rc, "octree deeper than %u levels (or cyclic)", RT_MAX_TREE_DEPTH);
+        case RT_NODE_ERROR_TOO_MANY: return fail(rc, "node buffer describes more than %zu nodes (shared or cyclic children)", n_words);
+        case RT_NODE_ERROR_RECORD_LIMIT: return fail(rc, "octree needs more than %u node records", RT_MAX_NODE_RECORDS);
+        default: return fail(rc, "node records: %s", hipGetErrorString((hipError_t)nb.hip_error));
+        }
+    }
+    s->d_nodes = nb.nodes;
+    t_flatten = ms_since(t_phase); t_phase = now();
+    if (n_ref) {
+        hipError_t e = hipMalloc(&s->d_tris, n_ref * sizeof(RtTriRec));
+        if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes, (RtTriRec *)s->d_tris);
+        if (e != hipSuccess) { rt_scene_destroy(s); return fail(e == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "triangle records: %s", hipGetErrorString(e)); }
     }
     if (hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_counters, 0, 64) != hipSuccess) {
         rt_scene_destroy(s);
@@ -339,11 +284,12 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     }
     s->d.vertices = (const float *)s->d_vertices; s->d.normals = (const float *)s->d_normals; s->d.tri_refs = (const uint32_t *)s->d_refs;
     s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.sky = nullptr;
-    s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = (uint32_t)recs.size();
+    s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = nb.n_nodes;
     s->d.sky_w = s->d.sky_h = 0;
     for (int k = 0; k < 3; k++) { s->d.bounds_min[k] = bounds_min[k]; s->d.bounds_max[k] = bounds_max[k]; }
-    s->d.max_depth = max_depth;
+    s->d.max_depth = nb.max_depth;
     *out = s;
+    if (trace) fprintf(stderr, "rt_scene_create ms: reference check %.1f | upload %.1f | node records %.1f (%u) | triangle records %.1f\n", t_check, t_upload, t_flatten, nb.n_nodes, ms_since(t_phase));
     return RT_OK;
 }
 

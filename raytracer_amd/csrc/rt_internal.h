@@ -8,7 +8,7 @@
 // One octree node as the device sees it: a single 64-byte line holding everything a visit needs -- header,
 // triangle range, the record index of its block of children and the node's own box with its midpoint, from which
 // child boxes are derived by midpoint split exactly as the reference shader does (ray_tracer.frag:487-500; the midpoint
-// (max+min)/2 is computed on the host with the same two IEEE operations).  Records are laid out breadth-first; a node
+// (max+min)/2 is computed ahead of time with the same two IEEE operations).  Records are laid out breadth-first; a node
 // with children owns a block of eight consecutive records, the child in octant o being record first_child + o (the
 // slots of children that do not exist are never read), so a visit turns "octant passes the slab test" into a record
 // index without counting mask bits.  A leaf (no children, so no child boxes to derive) carries the record of its first
@@ -28,7 +28,7 @@ static_assert(sizeof(RtNodeRec) == 64, "node record must be one 64-byte line");
 #define RT_MAX_SUBFRAMES 8
 #define RT_MAX_NODE_RECORDS (1u << 24)   // a traversal stack entry packs a record index into 24 bits
 
-// One triangle reference prepared for Moeller-Trumbore: first vertex and the two edges, computed on the host with
+// One triangle reference prepared for Moeller-Trumbore: first vertex and the two edges, computed once per scene with
 // the same IEEE subtractions the shader performs per test (frag:256-257), so a test needs three 16-byte loads
 // instead of an index load followed by three dependent vertex gathers.
 struct alignas(16) RtTriRec {
@@ -116,6 +116,18 @@ struct RtProbe {
 // rt_kernels.hip
 size_t rt_render_units(uint32_t width, uint32_t n_local_rows);   // workgroups of the one-lane-per-pixel kernel
 size_t rt_pool_bytes();   // size of the persistent path kernel's tile-counter block
+// Scene set-up on the device: fills the n_ref triangle records (first vertex and the two edges, frag:256-257) from the
+// uploaded vertices and references, then copies every leaf's first triangle record into the leaf's node record.
+// Synchronous; returns a hipError_t value.
+// Node records from the uploaded node words, breadth-first with eight-slot child blocks; every offset the shader would
+// dereference is checked on the way.  RT_OK: `nodes` (hipMalloc'ed, the caller frees) holds n_nodes records.  RT_ESCENE /
+// RT_ELIMIT: `error` says what is wrong (1..5: the kinds below, at node word `error_word`).  RT_ENODEVICE: `hip_error`.
+#define RT_NODE_ERROR_TOO_DEEP 100u
+#define RT_NODE_ERROR_TOO_MANY 101u
+#define RT_NODE_ERROR_RECORD_LIMIT 102u
+struct RtNodeBuild { RtNodeRec *nodes; uint32_t n_nodes, max_depth, error, error_word; int hip_error; };
+int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3], RtNodeBuild *out);
+int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris);
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
 // pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:

@@ -1,0 +1,196 @@
+// Device-side scene set-up behind rt_scene_create: from the reference's arrays as uploaded (vertices, triangle references,
+// node words: app/core/src/Octree.cpp:44-75, read by the shader at app/assets/ray_tracer.frag:460-500) to the records the
+// render kernels traverse.  Compiled with the render kernels' arithmetic mode (no contraction, denormals flushed like the
+// shader's), because the child boxes and triangle edges computed here are the shader's own operations done ahead of time.
+//
+//   node records      the words are walked breadth-first, one tree level per pass: check_nodes_kernel validates every
+//                     offset the shader would dereference and says which nodes have children; a prefix sum gives each of
+//                     those a block of eight consecutive records in the next level (child in octant o = first_child + o,
+//                     slots of missing children stay zero); write_nodes_kernel writes the level's records and the next
+//                     level's (word offset, box) list.  The host only sees two counters per level.
+//   triangle records  first vertex and the two edges of every reference (frag:256-257, 469-471)
+//   leaf triangles    a leaf has no child boxes to derive, so its box fields carry its first triangle record instead
+//                     (nine floats either way): visiting a leaf with one triangle takes one memory round trip, not two
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace {
+
+constexpr uint32_t HOLE = 0xFFFFFFFFu;
+constexpr int BLOCK = 256;
+enum NodeError : uint32_t { E_NONE = 0, E_PAST_END, E_COUNT_MASK, E_COUNT_BITS, E_POINTERS_PAST_END, E_TRIANGLE_RANGE };
+
+struct Entry { uint32_t word; float lo[3], hi[3]; };            // a node of the level being written (word == HOLE: an empty slot)
+struct Tally { uint32_t blocks, children; };                   // nodes with children / child pointers before an entry
+struct AddTally { __host__ __device__ Tally operator()(const Tally &a, const Tally &b) const { return Tally{a.blocks + b.blocks, a.children + b.children}; } };
+
+__global__ __launch_bounds__(BLOCK) void check_nodes_kernel(const uint32_t *__restrict__ words, uint32_t n_words, uint32_t n_ref, const Entry *__restrict__ level, uint32_t n,
+                                                            Tally *__restrict__ tally, uint32_t *__restrict__ error) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j > n) return;
+    Tally t{0u, 0u};
+    if (j < n && level[j].word != HOLE) {
+        const uint32_t w = level[j].word;
+        uint32_t bad = E_NONE;
+        if ((unsigned long long)w + 2ull > n_words) bad = E_PAST_END;
+        else {
+            const uint32_t info = words[w], tri_start = words[w + 1];
+            const uint32_t count = info & 0xFu, mask = (info >> 8) & 0xFFu, tri_count = info >> 16;
+            if ((uint32_t)__popc(mask) != count) bad = E_COUNT_MASK;
+            else if ((info & 0xF0u) != 0u) bad = E_COUNT_BITS;
+            else if ((unsigned long long)w + 2ull + count > n_words) bad = E_POINTERS_PAST_END;
+            else if ((unsigned long long)tri_start + tri_count > n_ref) bad = E_TRIANGLE_RANGE;
+            else { t.blocks = count ? 1u : 0u; t.children = count; }
+        }
+        if (bad != E_NONE && atomicCAS(&error[0], 0u, bad) == 0u) error[1] = w;
+    }
+    tally[j] = t;       // entry n is the zero that makes the exclusive sum return the totals
+}
+
+__global__ __launch_bounds__(BLOCK) void write_nodes_kernel(const uint32_t *__restrict__ words, const Entry *__restrict__ level, uint32_t n, const Tally *__restrict__ before,
+                                                            uint32_t next_base, RtNodeRec *__restrict__ recs, Entry *__restrict__ next) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n) return;
+    RtNodeRec r{};
+    const Entry e = level[j];
+    if (e.word != HOLE) {
+        const uint32_t info = words[e.word], count = info & 0xFu, mask = (info >> 8) & 0xFFu;
+        r.info = info;
+        r.tri_start = words[e.word + 1];
+        for (int k = 0; k < 3; k++) { r.lo[k] = e.lo[k]; r.hi[k] = e.hi[k]; r.mid[k] = (e.hi[k] + e.lo[k]) / 2.0f; }   // frag:487
+        if (count) {
+            const uint32_t slot0 = 8u * before[j].blocks;
+            r.first_child = next_base + slot0;
+            uint32_t ci = 0;
+            for (uint32_t o = 0; o < 8u; o++) {
+                Entry c;
+                c.word = HOLE;
+                for (int k = 0; k < 3; k++) { c.lo[k] = 0.0f; c.hi[k] = 0.0f; }
+                if (mask & (1u << o)) {
+                    c.word = words[e.word + 2u + ci++];
+                    for (int k = 0; k < 3; k++) {   // frag:491-500
+                        const bool upper = (o >> k) & 1u;
+                        c.lo[k] = upper ? r.mid[k] : r.lo[k];
+                        c.hi[k] = upper ? r.hi[k] : r.mid[k];
+                    }
+                }
+                next[slot0 + o] = c;
+            }
+        }
+    }
+    recs[j] = r;
+}
+
+__global__ __launch_bounds__(BLOCK) void triangle_records_kernel(const float4 *__restrict__ vertices, const uint4 *__restrict__ refs, uint32_t n_ref, RtTriRec *__restrict__ tris) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_ref) return;
+    const uint4 t = refs[i];
+    const float4 a = vertices[t.x], b = vertices[t.y], c = vertices[t.z];   // frag:469-471
+    RtTriRec r;
+    r.v1[0] = a.x; r.v1[1] = a.y; r.v1[2] = a.z;
+    r.e1x = b.x - a.x; r.e1y = b.y - a.y; r.e1z = b.z - a.z;                // frag:256-257
+    r.e2x = c.x - a.x; r.e2y = c.y - a.y; r.e2z = c.z - a.z;
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    tris[i] = r;
+}
+
+__global__ __launch_bounds__(BLOCK) void leaf_triangle_kernel(RtNodeRec *__restrict__ nodes, uint32_t n_nodes, const RtTriRec *__restrict__ tris) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t info = nodes[i].info;
+    if ((info & 0xFu) != 0u || (info >> 16) == 0u) return;
+    const RtTriRec r = tris[nodes[i].tri_start];
+    nodes[i].lo[0] = r.v1[0]; nodes[i].lo[1] = r.v1[1]; nodes[i].lo[2] = r.v1[2];
+    nodes[i].mid[0] = r.e1x; nodes[i].mid[1] = r.e1y; nodes[i].mid[2] = r.e1z;
+    nodes[i].hi[0] = r.e2x; nodes[i].hi[1] = r.e2y; nodes[i].hi[2] = r.e2z;
+}
+
+inline uint32_t grid_for(size_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
+
+struct Buf {
+    void *p = nullptr;
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    Buf(Buf &&o) noexcept : p(o.p) { o.p = nullptr; }
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+}  // namespace
+
+#define REC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { out->hip_error = (int)e_; return RT_ENODEVICE; } } while (0)
+
+int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3], RtNodeBuild *out) {
+    out->nodes = nullptr; out->n_nodes = 0; out->max_depth = 0; out->error = 0; out->error_word = 0; out->hip_error = 0;
+    if (n_words == 0) return RT_OK;
+    if (n_words < 2) { out->error = E_PAST_END; out->error_word = 0; return RT_ESCENE; }
+    Buf level, next, tally, scan_tmp, error;
+    std::vector<Buf> chunks;             // the records of every level, concatenated at the end
+    std::vector<uint32_t> chunk_size;
+    REC_TRY(error.alloc(8));
+    REC_TRY(hipMemset(error.p, 0, 8));
+    Entry root;
+    root.word = 0u;
+    for (int k = 0; k < 3; k++) { root.lo[k] = lo0[k]; root.hi[k] = hi0[k]; }
+    REC_TRY(level.alloc(sizeof(Entry)));
+    REC_TRY(hipMemcpy(level.p, &root, sizeof root, hipMemcpyHostToDevice));
+    uint32_t n = 1, base = 0, depth = 0;
+    unsigned long long real_nodes = 1;   // a tree cannot hold more nodes than words: more means shared or cyclic children
+    for (;; depth++) {
+        REC_TRY(tally.alloc(((size_t)n + 1) * sizeof(Tally)));
+        hipLaunchKernelGGL(check_nodes_kernel, dim3(grid_for((size_t)n + 1)), dim3(BLOCK), 0, nullptr, d_words, (uint32_t)n_words, (uint32_t)n_ref, (const Entry *)level.p, n, (Tally *)tally.p, (uint32_t *)error.p);
+        REC_TRY(hipGetLastError());
+        {
+            size_t bytes = 0;
+            REC_TRY(hipcub::DeviceScan::ExclusiveScan(nullptr, bytes, (const Tally *)tally.p, (Tally *)tally.p, AddTally(), Tally{0u, 0u}, (int)(n + 1), nullptr));
+            REC_TRY(scan_tmp.alloc(bytes));
+            REC_TRY(hipcub::DeviceScan::ExclusiveScan(scan_tmp.p, bytes, (const Tally *)tally.p, (Tally *)tally.p, AddTally(), Tally{0u, 0u}, (int)(n + 1), nullptr));
+        }
+        Tally total{0u, 0u};
+        uint32_t err[2] = {0u, 0u};
+        REC_TRY(hipMemcpy(&total, (const Tally *)tally.p + n, sizeof total, hipMemcpyDeviceToHost));
+        REC_TRY(hipMemcpy(err, error.p, sizeof err, hipMemcpyDeviceToHost));
+        if (err[0]) { out->error = err[0]; out->error_word = err[1]; return RT_ESCENE; }
+        real_nodes += total.children;
+        if (total.blocks && depth + 1 > RT_MAX_TREE_DEPTH) { out->error = RT_NODE_ERROR_TOO_DEEP; return RT_ESCENE; }
+        if (real_nodes > n_words) { out->error = RT_NODE_ERROR_TOO_MANY; return RT_ESCENE; }
+        const unsigned long long next_n = 8ull * total.blocks;
+        if ((unsigned long long)base + n + next_n > RT_MAX_NODE_RECORDS) { out->error = RT_NODE_ERROR_RECORD_LIMIT; return RT_ELIMIT; }
+        chunks.emplace_back();
+        chunk_size.push_back(n);
+        REC_TRY(chunks.back().alloc((size_t)n * sizeof(RtNodeRec)));
+        REC_TRY(next.alloc((size_t)next_n * sizeof(Entry)));
+        hipLaunchKernelGGL(write_nodes_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, d_words, (const Entry *)level.p, n, (const Tally *)tally.p, base + n, (RtNodeRec *)chunks.back().p, (Entry *)next.p);
+        REC_TRY(hipGetLastError());
+        out->max_depth = depth;
+        base += n;
+        if (next_n == 0) break;
+        REC_TRY(hipDeviceSynchronize());      // `level` is released below while the kernel may still read it
+        std::swap(level.p, next.p);
+        n = (uint32_t)next_n;
+    }
+    void *all = nullptr;
+    REC_TRY(hipMalloc(&all, (size_t)base * sizeof(RtNodeRec)));
+    size_t at = 0;
+    for (size_t l = 0; l < chunks.size(); l++) {
+        hipError_t e = hipMemcpy((char *)all + at, chunks[l].p, (size_t)chunk_size[l] * sizeof(RtNodeRec), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { (void)hipFree(all); out->hip_error = (int)e; return RT_ENODEVICE; }
+        at += (size_t)chunk_size[l] * sizeof(RtNodeRec);
+    }
+    out->nodes = (RtNodeRec *)all;
+    out->n_nodes = base;
+    return RT_OK;
+}
+
+int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris) {
+    if (n_ref) hipLaunchKernelGGL(triangle_records_kernel, dim3(grid_for(n_ref)), dim3(BLOCK), 0, nullptr, (const float4 *)vertices, (const uint4 *)tri_refs, n_ref, tris);
+    if (n_ref && n_nodes) hipLaunchKernelGGL(leaf_triangle_kernel, dim3(grid_for(n_nodes)), dim3(BLOCK), 0, nullptr, nodes, n_nodes, (const RtTriRec *)tris);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return (int)e;
+}
