@@ -11,6 +11,9 @@ Fixtures
                           primary hit (kind, triangle-reference slot / sphere index, t), segment count and final RNG seed
   ref_math.npz            llvmpipe's sin/cos/pow and cubemap lookups on probe inputs (own probe shader text)
   ref_accum.npz           4 progressively blended frames (time varies), final colour
+  refscene_<name>.npz     the same record for scenes other than the bunny, stored WITH their scene arrays (vertices, normals,
+                          triangle references, node words, bounds): a cluster of small meshes carrying all seven materials
+                          on triangles, and the reference's quad mesh assets/suzanne.obj (as triangulated by oracle.parse_obj)
   ref_ndc_640x512.npz     the interpolated NDC varying at the reference's own window size (not a power of two, so it
                           differs from the closed form): int32 ulp deltas, plus reference taps/colour for a band of rows
 """
@@ -143,7 +146,59 @@ def math_fixture(sky):
                 dirs=d, sky_rgb=out[n:, :3].copy(), sky=sky)
 
 
+def materials_scene() -> dict:
+    """60 small icospheres and boxes around (0, 1.5, 0), materials 0..6 cycling: every material on mesh triangles."""
+    from raytracer_amd import scenes
+    meshes = scenes.synthetic_primitives(60, seed=3, sphere_subdiv=1, extent=1.5, centre=(0.0, 1.5, 0.0), size_range=(0.1, 0.35), materials=(0, 1, 2, 3, 4, 5, 6))
+    verts, norms, tris, base = [], [], [], 0
+    for m in meshes:                                  # merged as Octree.cpp:221-233 merges its meshes
+        verts.append(m.m_vertecies); norms.append(m.m_normals)
+        t = m.m_triangles.copy(); t[:, :3] += base
+        tris.append(t); base += len(m.m_vertecies)
+    v, n, t = np.concatenate(verts), np.concatenate(norms), np.concatenate(tris)
+    o = oracle.octree_build(v, t, 10, 10, 6, 6)
+    return dict(vertices=v, normals=n, tri_refs=o["tri_refs"], nodes=o["nodes"], bounds_min=o["bounds_min"], bounds_max=o["bounds_max"])
+
+
+def suzanne_scene(material_id: int) -> dict:
+    pos, nrm, faces = oracle.parse_obj("/root/reference/app/assets/suzanne.obj")
+    T = np.eye(4, dtype=np.float32)          # the mesh sits around (-2.5, 1.25, 4.1) in its own coordinates
+    v, n, t = oracle.mesh_build(pos, nrm, faces, material_id, T)
+    o = oracle.octree_build(v, t, 18, 10, 6, 6)
+    return dict(vertices=v, normals=n, tri_refs=o["tri_refs"], nodes=o["nodes"], bounds_min=o["bounds_min"], bounds_max=o["bounds_max"])
+
+
+# (power-of-two frame sizes: there the rasteriser's interpolated NDC equals the closed form, see ref_ndc_640x512.npz for the other case)
+SCENE_VIEWS = {
+    "materials_a": dict(scene="materials", cam=Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=1.0), size=(128, 128)),
+    "materials_b": dict(scene="materials", cam=Camera(eye=(1.3, 2.3, 1.5), at=(0.0, 1.5, 0.0), fovy=1.2, aspect=2.0), size=(256, 128), kw=dict(max_recursion_limit=8)),
+    "suzanne_glass": dict(scene="suzanne5", cam=Camera(eye=(-1.3, 1.9, 6.4), at=(-2.5, 1.25, 4.1), aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=8)),
+    "suzanne_metal": dict(scene="suzanne2", cam=Camera(eye=(-4.6, 2.4, 5.9), at=(-2.5, 1.25, 4.1), aspect=1.0), size=(128, 128)),
+}
+
+
+def scene_fixtures():
+    """refscene_<name>.npz: reference records of scenes other than the bunny, with the scene arrays inside."""
+    sky = fixture_sky()
+    built = {"materials": materials_scene(), "suzanne5": suzanne_scene(5), "suzanne2": suzanne_scene(2)}
+    for name, v in SCENE_VIEWS.items():
+        scene = built[v["scene"]]
+        w, h = v["size"]
+        u = Uniforms.from_camera(v["cam"], **v.get("kw", {})).pack()
+        rec = reference_record(scene, u, w, h, sky)
+        rec.update({"scene_" + k: a for k, a in scene.items()})
+        np.savez_compressed(os.path.join(GOLDEN, f"refscene_{name}.npz"), **rec)
+        tri = rec["kind"] == 2
+        print(name, w, h, "kinds", np.bincount(rec["kind"].ravel(), minlength=6), "materials of primary triangle hits", np.unique(scene["tri_refs"].reshape(-1, 4)[rec["slot"][tri], 3]).tolist(),
+              "max segments", int(rec["nrays"].max()), os.path.getsize(os.path.join(GOLDEN, f"refscene_{name}.npz")))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "scenes":      # only the refscene_* set
+        refrun.build()
+        assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+        scene_fixtures()
+        return
     refrun.build()
     assert refrun.available(), "needs /root/reference and the llvmpipe runner"
     os.makedirs(GOLDEN, exist_ok=True)
@@ -176,6 +231,7 @@ def main():
     rec["ndc_dx"], rec["ndc_dy"] = dx.astype(np.int32), dy.astype(np.int32)
     np.savez_compressed(os.path.join(GOLDEN, "ref_ndc_640x512.npz"), **rec)
     print("ndc 640x512: x differs on %.1f%% of pixels, y on %.1f%%" % (100 * (dx != 0).mean(), 100 * (dy != 0).mean()))
+    scene_fixtures()
     total = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
     print("fixtures total bytes:", total)
 

@@ -50,6 +50,24 @@ def test_hip_matches_llvmpipe_view(gpu_scene, path):
     check(gpu_scene.render(z["uniforms"], w, h), z)
 
 
+SCENE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "refscene_*.npz")))
+
+
+@pytest.mark.parametrize("pipeline", ["persistent", "wavefront", "megakernel"])
+@pytest.mark.parametrize("path", SCENE_FILES, ids=[os.path.basename(p)[9:-4] for p in SCENE_FILES])
+def test_hip_matches_llvmpipe_on_other_scenes(path, pipeline):
+    """Scenes other than the bunny, stored with their arrays: every material on mesh triangles, the reference's quad mesh."""
+    z = np.load(path)
+    w, h = (int(v) for v in z["size"])
+    sc = api.Scene.from_dict({k[6:]: z[k] for k in z.files if k.startswith("scene_")})
+    sc.set_skybox(z["sky"])
+    sc.set_pipeline(pipeline)
+    try:
+        check(sc.render(z["uniforms"], w, h), z)
+    finally:
+        sc.close()
+
+
 def test_hip_matches_llvmpipe_accumulation(gpu_scene):
     z = np.load(os.path.join(GOLDEN, "ref_accum.npz"))
     w, h = (int(v) for v in z["size"])

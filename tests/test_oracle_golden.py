@@ -44,6 +44,34 @@ def test_oracle_matches_reference_view(scene, path):
     check_record(o, z)
 
 
+SCENE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "refscene_*.npz")))
+
+
+def scene_of(z):
+    return {k[6:]: z[k] for k in z.files if k.startswith("scene_")}
+
+
+@pytest.mark.parametrize("path", SCENE_FILES, ids=[os.path.basename(p)[9:-4] for p in SCENE_FILES])
+def test_oracle_matches_reference_on_other_scenes(path):
+    """Reference records of scenes other than the bunny (all seven materials on mesh triangles; the reference's quad mesh),
+    stored with their scene arrays."""
+    z = np.load(path)
+    w, h = (int(v) for v in z["size"])
+    o = oracle.OracleScene(scene_of(z), z["sky"]).render(z["uniforms"], w, h)
+    check_record(o, z)
+
+
+def test_scene_fixture_coverage():
+    assert len(SCENE_FILES) >= 4
+    mats = set()
+    for p in SCENE_FILES:
+        z = np.load(p)
+        tri = z["kind"] == 2
+        assert tri.sum() > 1000
+        mats |= set(np.unique(z["scene_tri_refs"].reshape(-1, 4)[z["slot"][tri], 3]).tolist())
+    assert mats == {0, 1, 2, 3, 4, 5, 6}
+
+
 def test_fixture_coverage():
     """The views together exercise every hit kind and every path length up to the recursion limit."""
     kinds, nrays = set(), set()
