@@ -45,6 +45,14 @@ VIEWS = {
     "topdown": dict(cam=Camera(eye=(0.1, 9.0, 0.1), at=(0.0, 0.0, 0.0), aspect=1.0), size=(128, 128)),
     "maxrec2": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=2)),
     "maxrec8": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=8, blur_amount=0.01)),
+    # edge cases: no segment at all, primary only, a camera 96 units out (beyond the distance up to which the product culls
+    # spheres), a camera inside a big sphere, a large time value, a strong lens blur
+    "maxrec0": dict(cam=Camera(aspect=1.0), size=(64, 64), kw=dict(max_recursion_limit=0)),
+    "maxrec1": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=1)),
+    "far": dict(cam=Camera(eye=(60.0, 45.0, 60.0), at=(0.0, 1.0, 0.0), fovy=0.2, aspect=1.0), size=(128, 128)),
+    "inside_sphere": dict(cam=Camera(eye=(-4.0, 2.0, 0.3), at=(0.0, 2.0, 0.0), aspect=1.0), size=(128, 128)),
+    "bigtime": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(time=12345.678)),
+    "blur": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(blur_amount=0.2)),
 }
 
 
@@ -194,6 +202,17 @@ def scene_fixtures():
 
 
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "views":       # only the named bunny views
+        refrun.build()
+        assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+        scene, sky = bunny_scene(), fixture_sky()
+        for name in sys.argv[2:]:
+            v = VIEWS[name]
+            w, h = v["size"]
+            rec = reference_record(scene, Uniforms.from_camera(v["cam"], **v.get("kw", {})).pack(), w, h, sky)
+            np.savez_compressed(os.path.join(GOLDEN, f"ref_{name}.npz"), **rec)
+            print(name, w, h, "kinds", np.bincount(rec["kind"].ravel(), minlength=6), "max segments", int(rec["nrays"].max()))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "scenes":      # only the refscene_* set
         refrun.build()
         assert refrun.available(), "needs /root/reference and the llvmpipe runner"

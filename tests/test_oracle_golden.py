@@ -29,7 +29,8 @@ def check_record(o, z, rows=None):
     assert np.array_equal(o["kind"][sl], z["kind"])
     assert np.array_equal(o["slot"][sl], z["slot"])
     assert np.array_equal(o["nrays"][sl], z["nrays"])
-    assert np.array_equal(bits(o["t"][sl]), bits(z["t"]))
+    traced = z["nrays"] > 0          # with no segment at all (max_recursion_limit 0) there is no primary hit distance to compare
+    assert np.array_equal(bits(o["t"][sl])[traced], bits(z["t"])[traced])
     assert np.array_equal(bits(o["seed"][sl]), bits(z["seed"]))
     assert np.array_equal(bits(o["depth"][sl]), bits(z["depth"]))
     assert np.array_equal(bits(o["rgba"][sl][..., :3]), bits(z["rgb"]))
