@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import oracle, refrun  # noqa: E402
-from raytracer_amd.camera import Camera  # noqa: E402
+from raytracer_amd.camera import Camera, Portals, normalize  # noqa: E402
 from raytracer_amd.params import Uniforms  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -53,6 +53,10 @@ VIEWS = {
     "inside_sphere": dict(cam=Camera(eye=(-4.0, 2.0, 0.3), at=(0.0, 2.0, 0.0), aspect=1.0), size=(128, 128)),
     "bigtime": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(time=12345.678)),
     "blur": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(blur_amount=0.2)),
+    # portals away from their default places, neither axis-aligned: both difference matrices are general rotations
+    "portal_custom": dict(cam=Camera(eye=(2.0, 2.0, 3.5), at=(0.0, 1.5, 0.0), aspect=1.0), size=(128, 128),
+                          kw=dict(portals=Portals(position_1=(0.9, 1.9, 2.2), direction_1=tuple(normalize((0.3, 0.0, 1.0)).astype(np.float32).tolist()),
+                                                  position_2=(-2.5, 1.6, -1.0), direction_2=tuple(normalize((1.0, 0.2, 0.1)).astype(np.float32).tolist()), width=1.4, height=1.8))),
 }
 
 
