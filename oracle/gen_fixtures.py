@@ -10,6 +10,7 @@ Fixtures
   ref_<view>.npz          per view: uniforms, sky, size; reference colour (rgb f32), gl_FragDepth, and taps of the
                           primary hit (kind, triangle-reference slot / sphere index, t), segment count and final RNG seed
   ref_math.npz            llvmpipe's sin/cos/pow and cubemap lookups on probe inputs (own probe shader text)
+  ref_sky_sizes.npz       cubemap lookups at face sizes 9, 30 and 100 (own probe shader text)
   ref_accum.npz           4 progressively blended frames (time varies), final colour
   refscene_<name>.npz     the same record for scenes other than the bunny, stored WITH their scene arrays (vertices, normals,
                           triangle references, node words, bounds): a cluster of small meshes carrying all seven materials
@@ -205,7 +206,31 @@ def scene_fixtures():
               "max segments", int(rec["nrays"].max()), os.path.getsize(os.path.join(GOLDEN, f"refscene_{name}.npz")))
 
 
+def sky_size_fixture():
+    """ref_sky_sizes.npz: cubemap lookups at face sizes that are not powers of two (the reference's faces are 900 x 900; the
+    texel arithmetic scales coordinates by the size), on directions that include face edges and corners."""
+    rng = np.random.default_rng(9)
+    n = 32 * 64
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d[:6] = np.array([[1, 1, 1], [1, -1, 1], [-1, 1, -1], [1, 0.999999, 0.5], [0.3, -1, -1], [-1, -1, -0.999999]], np.float32)
+    x = np.zeros((64 * 64, 4), np.float32)
+    x[32 * 64:, :3] = d
+    rec = {"dirs": d}
+    for size in (9, 30, 100):
+        sky = np.random.default_rng(100 + size).integers(0, 256, size=(6, size, size, 4), dtype=np.uint8)
+        out = refrun.run_probe(MATH_FRAG, x, 64, 64, sky=sky).reshape(-1, 4)
+        rec[f"sky_{size}"] = sky
+        rec[f"rgb_{size}"] = out[32 * 64:, :3].copy()
+    np.savez_compressed(os.path.join(GOLDEN, "ref_sky_sizes.npz"), **rec)
+    print("sky sizes", os.path.getsize(os.path.join(GOLDEN, "ref_sky_sizes.npz")))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sky":
+        refrun.build()
+        assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+        sky_size_fixture()
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "views":       # only the named bunny views
         refrun.build()
         assert refrun.available(), "needs /root/reference and the llvmpipe runner"
@@ -255,6 +280,7 @@ def main():
     np.savez_compressed(os.path.join(GOLDEN, "ref_ndc_640x512.npz"), **rec)
     print("ndc 640x512: x differs on %.1f%% of pixels, y on %.1f%%" % (100 * (dx != 0).mean(), 100 * (dy != 0).mean()))
     scene_fixtures()
+    sky_size_fixture()
     total = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
     print("fixtures total bytes:", total)
 

@@ -287,3 +287,19 @@ def test_batched_sequence_of_small_frames(bunny_octree, test_sky):
             for k in ref:
                 assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (band, batch, k)
     sc.close()
+
+
+@pytest.mark.parametrize("size", [9, 30, 900])
+def test_skybox_face_sizes(bunny_octree, size):
+    """The environment lookup scales coordinates by the face size: sizes that are not powers of two, and the reference's
+    own 900 x 900 (the oracle's lookup is pinned to llvmpipe at 9, 30 and 100 by tests/golden/ref_sky_sizes.npz)."""
+    from oracle import oracle
+    sky = scenes.procedural_skybox(size) if size == 900 else np.random.default_rng(size).integers(0, 256, size=(6, size, size, 4), dtype=np.uint8)
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(sky)
+    osc = oracle.OracleScene(bunny_octree.as_dict(), sky)
+    u = Uniforms.from_camera(Camera(eye=(2.0, 1.0, 2.0), at=(0.0, 3.0, 0.0), aspect=1.0)).pack()      # looking up: mostly sky
+    o = osc.render(u, 128, 128)
+    assert (o["kind"] == api.HIT_MISS).mean() > 0.3
+    compare(o, sc.render(u, 128, 128), size)
+    sc.close()

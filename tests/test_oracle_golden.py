@@ -12,7 +12,7 @@ from oracle import oracle
 from oracle.gen_fixtures import apply_ulp_delta, closed_form_ndc, bunny_scene
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_math.npz", "ref_ndc_640x512.npz"))
+VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_math.npz", "ref_ndc_640x512.npz", "ref_sky_sizes.npz"))
 
 
 def bits(a):
@@ -126,3 +126,11 @@ def test_oracle_cubemap_matches_llvmpipe():
     empty = dict(vertices=np.zeros((1, 4)), normals=np.zeros((1, 4)), tri_refs=np.zeros((1, 4)), nodes=np.zeros(0), bounds_min=[0, 0, 0], bounds_max=[0, 0, 0])
     o = oracle.OracleScene(empty, z["sky"]).sample_sky(z["dirs"])
     assert np.array_equal(bits(o), bits(z["sky_rgb"]))
+
+
+@pytest.mark.parametrize("size", [9, 30, 100])
+def test_oracle_cubemap_at_other_face_sizes(size):
+    z = np.load(os.path.join(GOLDEN, "ref_sky_sizes.npz"))
+    empty = dict(vertices=np.zeros((1, 4)), normals=np.zeros((1, 4)), tri_refs=np.zeros((1, 4)), nodes=np.zeros(0), bounds_min=[0, 0, 0], bounds_max=[0, 0, 0])
+    o = oracle.OracleScene(empty, z[f"sky_{size}"]).sample_sky(z["dirs"])
+    assert np.array_equal(bits(o), bits(z[f"rgb_{size}"]))
