@@ -54,6 +54,8 @@ VIEWS = {
     "inside_sphere": dict(cam=Camera(eye=(-4.0, 2.0, 0.3), at=(0.0, 2.0, 0.0), aspect=1.0), size=(128, 128)),
     "bigtime": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(time=12345.678)),
     "blur": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(blur_amount=0.2)),
+    # other clip planes: gl_FragDepth is a function of z_near / z_far (frag:352-354), hits beyond z_far clamp to 1
+    "depthrange": dict(cam=Camera(aspect=1.0, z_near=0.5, z_far=6.0), size=(128, 128)),
     # portals away from their default places, neither axis-aligned: both difference matrices are general rotations
     "portal_custom": dict(cam=Camera(eye=(2.0, 2.0, 3.5), at=(0.0, 1.5, 0.0), aspect=1.0), size=(128, 128),
                           kw=dict(portals=Portals(position_1=(0.9, 1.9, 2.2), direction_1=tuple(normalize((0.3, 0.0, 1.0)).astype(np.float32).tolist()),
@@ -186,6 +188,7 @@ SCENE_VIEWS = {
     "materials_a": dict(scene="materials", cam=Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=1.0), size=(128, 128)),
     "materials_b": dict(scene="materials", cam=Camera(eye=(1.3, 2.3, 1.5), at=(0.0, 1.5, 0.0), fovy=1.2, aspect=2.0), size=(256, 128), kw=dict(max_recursion_limit=8)),
     "suzanne_glass": dict(scene="suzanne5", cam=Camera(eye=(-1.3, 1.9, 6.4), at=(-2.5, 1.25, 4.1), aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=8)),
+    "empty": dict(scene="empty", cam=Camera(aspect=1.0), size=(128, 128)),
     "suzanne_metal": dict(scene="suzanne2", cam=Camera(eye=(-4.6, 2.4, 5.9), at=(-2.5, 1.25, 4.1), aspect=1.0), size=(128, 128)),
 }
 
@@ -193,8 +196,14 @@ SCENE_VIEWS = {
 def scene_fixtures():
     """refscene_<name>.npz: reference records of scenes other than the bunny, with the scene arrays inside."""
     sky = fixture_sky()
-    built = {"materials": materials_scene(), "suzanne5": suzanne_scene(5), "suzanne2": suzanne_scene(2)}
+    # no mesh at all: a root leaf without triangles in a box of zero size (never entered)
+    empty = dict(vertices=np.zeros((1, 4), np.float32), normals=np.zeros((1, 4), np.float32), tri_refs=np.zeros((1, 4), np.uint32), nodes=np.zeros(2, np.uint32),
+                 bounds_min=np.zeros(3, np.float32), bounds_max=np.zeros(3, np.float32))
+    built = {"materials": materials_scene(), "suzanne5": suzanne_scene(5), "suzanne2": suzanne_scene(2), "empty": empty}
+    only = sys.argv[2:] if len(sys.argv) > 2 else None
     for name, v in SCENE_VIEWS.items():
+        if only and name not in only:
+            continue
         scene = built[v["scene"]]
         w, h = v["size"]
         u = Uniforms.from_camera(v["cam"], **v.get("kw", {})).pack()
@@ -202,7 +211,7 @@ def scene_fixtures():
         rec.update({"scene_" + k: a for k, a in scene.items()})
         np.savez_compressed(os.path.join(GOLDEN, f"refscene_{name}.npz"), **rec)
         tri = rec["kind"] == 2
-        print(name, w, h, "kinds", np.bincount(rec["kind"].ravel(), minlength=6), "materials of primary triangle hits", np.unique(scene["tri_refs"].reshape(-1, 4)[rec["slot"][tri], 3]).tolist(),
+        print(name, w, h, "kinds", np.bincount(rec["kind"].ravel(), minlength=6), "materials of primary triangle hits", np.unique(np.asarray(scene["tri_refs"]).reshape(-1, 4)[rec["slot"][tri], 3]).tolist(),
               "max segments", int(rec["nrays"].max()), os.path.getsize(os.path.join(GOLDEN, f"refscene_{name}.npz")))
 
 

@@ -63,11 +63,14 @@ def test_oracle_matches_reference_on_other_scenes(path):
 
 
 def test_scene_fixture_coverage():
-    assert len(SCENE_FILES) >= 4
+    assert len(SCENE_FILES) >= 5
     mats = set()
     for p in SCENE_FILES:
         z = np.load(p)
         tri = z["kind"] == 2
+        if os.path.basename(p) == "refscene_empty.npz":
+            assert tri.sum() == 0
+            continue
         assert tri.sum() > 1000
         mats |= set(np.unique(z["scene_tri_refs"].reshape(-1, 4)[z["slot"][tri], 3]).tolist())
     assert mats == {0, 1, 2, 3, 4, 5, 6}
