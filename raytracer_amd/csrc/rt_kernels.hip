@@ -927,16 +927,17 @@ DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
 // Pipeline 1: one kernel, one lane per pixel for the whole path (kept as the simple cross-check).
 // ================================================================================================
 // Resident waves per SIMD the register allocator must make room for.  The kernel hides the latency of its dependent
-// node and triangle loads only through other waves, so six waves with a few spilled registers beat four without
-// (measured: 1.10 vs 1.24 ms per 4K frame); six is also what the LDS allows (a 20-level stack is 80 bytes per lane,
-// plus 3.2 KB of sphere data per workgroup: twelve 128-thread workgroups per CU).
+// node and triangle loads only through other waves: 4 / 5 / 6 / 7 waves per SIMD give 0.74 / 0.65 / 0.59 / 0.57 ms per 4K
+// frame.  Seven is what a CU's LDS allows when the stack has at most 19 levels (76 bytes per lane, plus 3.4 KB of sphere
+// and portal data shared by the four waves of a workgroup: seven 256-thread workgroups); it leaves 72 registers, one of
+// which is spilled.  A 20-level stack fits six workgroups; the variant for very deep trees needs 46 KB per workgroup,
+// three fit, and it keeps its registers.
 #ifndef RENDER_WAVES_PER_SIMD
 #define RENDER_WAVES_PER_SIMD 6
 #endif
-// (the variant for very deep trees needs 46 KB of LDS per workgroup: three fit, so it keeps its registers)
-#define RENDER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3, LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3)))
+#define RENDER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(LEVELS <= 19 ? 7 : LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3, LEVELS <= 19 ? 7 : LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3)))
 #ifndef RENDER_BLOCK
-#define RENDER_BLOCK 128   // threads per workgroup: a workgroup keeps its LDS until its slowest wave ends, so small ones free the CU sooner
+#define RENDER_BLOCK 256   // threads per workgroup = pixels per unit of the cost map (a 16x16 tile)
 #endif
 // BATCH: the launch traces B->n consecutive frames (see RtBatch), the expensive units of all frames still first.
 template <int LEVELS, bool COUNT, int BLOCK, bool BATCH>
@@ -1061,12 +1062,8 @@ template <int LEVELS, bool COUNT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_kernel(RtDeviceScene S, RtLaunch L) {
     render_body<LEVELS, COUNT, BLOCK, false>(S, L, nullptr);
 }
-// The batched kernel shares its sphere data among four waves, so with a stack of up to 19 levels SEVEN workgroups fit a
-// CU's LDS (22.8 KB each), and it is built for seven waves per SIMD (72 registers, one spilled): 0.593 -> 0.570 ms per
-// 4K frame at limit 2, 0.985 -> 0.926 at limit 5.
-#define BATCH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(LEVELS <= 19 ? 7 : LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3, LEVELS <= 19 ? 7 : LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3)))
 template <int LEVELS, bool COUNT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) BATCH_OCCUPANCY void render_batch_kernel(RtDeviceScene S, RtLaunch L, RtBatch B) {
+__global__ __launch_bounds__(BLOCK) RENDER_OCCUPANCY void render_batch_kernel(RtDeviceScene S, RtLaunch L, RtBatch B) {
     render_body<LEVELS, COUNT, BLOCK, true>(S, L, &B);
 }
 // Blends the staged samples of a batch into the target, frame after frame per pixel (App.cpp:49,102-105).
