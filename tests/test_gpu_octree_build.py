@@ -65,3 +65,37 @@ def test_large_synthetic_scene_equals_host_builder():
 def test_invalid_device_is_rejected():
     with pytest.raises(api.RtError):
         api.Octree([scenes.bunny_mesh()], device=99)
+
+
+@pytest.mark.parametrize("params", [(8, 10, 6, 6), (7, 3, 2, 8), (6, 0, 4, 1)])
+def test_many_keep_candidates_with_equal_overlap_counts(params):
+    """Hundreds of large triangles through the centre of the box overlap all eight children of the root and most children
+    further down: far more "keep" candidates than a node may hold, nearly all with the same overlap count, so the order
+    std::partial_sort leaves among equals decides which stay and in which order the rest are pushed down."""
+    rng = np.random.default_rng(12)
+    n_big, n_small = 400, 4000
+    big = rng.uniform(-1.0, 1.0, (n_big, 3, 3)) * np.array([1.0, 1.0, 0.05])          # thin slabs through the middle
+    big[: n_big // 4] = big[0]                                                          # a hundred identical triangles
+    small = rng.uniform(-1, 1, (n_small, 1, 3)) + rng.normal(0, 0.03, (n_small, 3, 3))
+    tri = np.concatenate([big, small])
+    order = rng.permutation(len(tri))
+    pos = tri[order].reshape(-1, 3).astype(np.float32)
+    faces = np.arange(3 * len(tri), dtype=np.uint32).reshape(-1, 3)
+    meshes = [api.Mesh(positions=pos, faces=faces, material_id=3)]
+    host, dev = api.Octree(meshes, *params), api.Octree(meshes, *params, device=0)
+    same(host, dev)
+    assert len(host.m_compressed_triangles) > 3 * len(tri)      # the slabs are referenced from many nodes
+
+
+def test_flat_mesh_and_huge_triangle():
+    """A mesh of zero thickness (its box is flat: strict comparisons in the overlap test matter) plus one triangle that
+    dwarfs the rest."""
+    g = np.linspace(-1, 1, 40, dtype=np.float32)
+    xx, yy = np.meshgrid(g, g)
+    pos = np.stack([xx.ravel(), yy.ravel(), np.zeros(xx.size, np.float32)], 1)
+    idx = np.arange(40 * 40).reshape(40, 40)
+    faces = np.concatenate([np.stack([idx[:-1, :-1], idx[:-1, 1:], idx[1:, :-1]], -1).reshape(-1, 3), np.stack([idx[1:, :-1], idx[:-1, 1:], idx[1:, 1:]], -1).reshape(-1, 3)]).astype(np.uint32)
+    flat = api.Mesh(positions=pos, faces=faces, material_id=1)
+    huge = api.Mesh(positions=np.array([[-50, -50, 0], [50, -50, 0], [0, 80, 0]], np.float32), faces=np.array([[0, 1, 2]], np.uint32), material_id=2)
+    for meshes in ([flat], [flat, huge]):
+        same(api.Octree(meshes, 12, 10, 6, 6), api.Octree(meshes, 12, 10, 6, 6, device=0))
