@@ -56,6 +56,25 @@ def test_builder_equals_oracle_on_random_soups(params, seed):
     assert o.max_depth == r["max_depth"]
 
 
+@pytest.mark.parametrize("params", [(8, 10, 6, 6), (7, 3, 2, 8), (6, 0, 4, 1)])
+def test_builder_equals_oracle_with_many_equal_keep_candidates(params):
+    """Far more "keep" candidates than a node may hold, nearly all with the same overlap count (thin slabs through the centre,
+    a hundred of them identical): which stay and in what order the rest go down is decided by the order std::partial_sort
+    leaves among equals (Octree.cpp:172-181)."""
+    rng = np.random.default_rng(12)
+    big = rng.uniform(-1.0, 1.0, (400, 3, 3)) * np.array([1.0, 1.0, 0.05])
+    big[:100] = big[0]
+    small = rng.uniform(-1, 1, (4000, 1, 3)) + rng.normal(0, 0.03, (4000, 3, 3))
+    tri = np.concatenate([big, small])
+    p = tri[rng.permutation(len(tri))].reshape(-1, 3).astype(np.float32)
+    f = np.arange(len(p), dtype=np.uint32).reshape(-1, 3)
+    m = api.Mesh(positions=p, faces=f, material_id=3)
+    ov, on, ot = oracle.mesh_build(p, None, f, 3, api.IDENTITY)
+    o = api.Octree([m], *params)
+    r = oracle.octree_build(ov, ot, *params)
+    assert np.array_equal(o.m_compressed_node_buffer, r["nodes"]) and np.array_equal(o.m_compressed_triangles, r["tri_refs"])
+
+
 def test_multi_mesh_merge_offsets_indices():
     rng = np.random.default_rng(5)
     p1, f1 = random_soup(rng, 500)
