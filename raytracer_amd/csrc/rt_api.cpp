@@ -188,6 +188,15 @@ extern "C" {
 const char *rt_last_error(void) { return g_err.c_str(); }
 int rt_internal_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
 
+// Verification hook (not part of the ABI): the kernels' short 1/x and sqrt sequences against the compiler's correctly rounded
+// ones over all 2^32 inputs; mismatches[0] = count, mismatches[1] = an input that differs.
+int rt_internal_math_check(int op, unsigned long long mismatches[2]) {
+    if (!mismatches || op < 0 || op > 1) return fail(RT_EINVAL, "bad argument");
+    hipError_t e = (hipError_t)rt_math_check(op, mismatches);
+    if (e != hipSuccess) return fail(RT_ENODEVICE, "math check: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 // Development hook (not part of the ABI): copies the tile-counter block of sub-frame 0 to the host.
 int rt_internal_read_pool(rt_scene *s, void *out, size_t bytes) {
     if (!s || !s->sub[0].pool || bytes > rt_pool_bytes()) return fail(RT_EINVAL, "no pool");

@@ -115,6 +115,7 @@ struct RtProbe {
 
 // rt_kernels.hip
 size_t rt_render_units(uint32_t width, uint32_t n_local_rows);   // workgroups of the one-lane-per-pixel kernel
+int rt_math_check(int op, unsigned long long out[2]);   // exhaustive check of the kernels' 1/x (0) and sqrt (1): see rt_kernels.hip
 size_t rt_pool_bytes();   // size of the persistent path kernel's tile-counter block
 // Scene set-up on the device: fills the n_ref triangle records (first vertex and the two edges, frag:256-257) from the
 // uploaded vertices and references, then copies every leaf's first triangle record into the leaf's node record.

@@ -30,9 +30,38 @@ DEVI f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
 DEVI float dot3(f3 a, f3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
 DEVI f3 cross3(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 // IEEE-correct square root, divide and reciprocal: hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt)
-DEVI float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
-DEVI float rcp_ieee(float x) { return 1.0f / x; }
-DEVI float div_ieee(float a, float b) { return a / b; }
+DEVI float sqrt_slow(float x) { return __builtin_sqrtf(x); }
+DEVI float rcp_slow(float x) { return 1.0f / x; }
+DEVI float div_slow(float a, float b) { return a / b; }
+#ifdef RT_SLOW_MATH
+DEVI float sqrt_ieee(float x) { return sqrt_slow(x); }
+DEVI float rcp_ieee(float x) { return rcp_slow(x); }
+#else
+// The compiler's correctly rounded 1/x and sqrt(x) are sequences of about a dozen instructions between two switches of
+// the denormal mode.  The hardware's own approximations (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp) followed by ONE Newton
+// step in fused arithmetic give the same bits for EVERY one of the 2^32 inputs under this file's arithmetic mode
+// (denormal inputs and results flushed) -- checked exhaustively on the device by rt_internal_math_check, which the GPU
+// tests run.  The residuals are exact (fused), so the step lands within a rounding error far smaller than the distance of
+// 1/x or sqrt(x) from a rounding boundary; zero, infinity and NaN make the residual NaN and keep the approximation.
+DEVI float rcp_ieee(float x) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e, r0, r0);
+    return e != e ? r0 : r1;
+}
+DEVI float sqrt_ieee(float x) {
+    // below 2^-95 the residual of the step would be flushed: such inputs are scaled by 2^64 (exact) and the root by 2^-32
+    const bool small = x < 0x1p-64f;
+    const float xs = small ? x * 0x1p+64f : x;
+    const float s0 = __builtin_amdgcn_sqrtf(xs);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(xs);
+    const float e = __builtin_fmaf(-s0, s0, xs);
+    const float s1 = __builtin_fmaf(e, h, s0);
+    const float s = s1 != s1 ? s0 : s1;
+    return small ? s * 0x1p-32f : s;
+}
+#endif
+DEVI float div_ieee(float a, float b) { return div_slow(a, b); }
 DEVI float length3(f3 a) { return sqrt_ieee(dot3(a, a)); }
 DEVI f3 normalize3(f3 a) { float inv = rcp_ieee(sqrt_ieee(dot3(a, a))); return a * inv; }
 DEVI f3 rcp3(f3 a) { return F3(rcp_ieee(a.x), rcp_ieee(a.y), rcp_ieee(a.z)); }
@@ -702,7 +731,9 @@ DEVI f3 sample_sky(const RtDeviceScene &S, f3 d) {
     if (z_sel) { ma = d.z; const bool neg = (f2u(ma) >> 31) != 0; face = 4 + (neg ? 1 : 0); sc = neg ? -d.x : d.x; tc = -d.y; }
     else if (x_over_y) { ma = d.x; const bool neg = (f2u(ma) >> 31) != 0; face = 0 + (neg ? 1 : 0); sc = neg ? d.z : -d.z; tc = -d.y; }
     else { ma = d.y; const bool neg = (f2u(ma) >> 31) != 0; face = 2 + (neg ? 1 : 0); sc = d.x; tc = neg ? -d.z : d.z; }
-    const float ima = div_ieee(0.5f, __builtin_fabsf(ma));   // projection: coord * (0.5 / |ma|) + 0.5
+    // projection: coord * (0.5 / |ma|) + 0.5; 0.5 / x and 0.5 * (1 / x) round alike (a power of two scales exactly, and a
+    // result too small to be normal is flushed either way)
+    const float ima = 0.5f * rcp_ieee(__builtin_fabsf(ma));
     const float s = ima * sc + 0.5f;
     const float t = ima * tc + 0.5f;
     const int W = S.sky_w, H = S.sky_h;
@@ -1567,6 +1598,32 @@ size_t rt_pool_bytes() { return (size_t)PATH_POOLS * PATH_POOL_STRIDE * sizeof(u
 #else
 size_t rt_pool_bytes() { return (size_t)PATH_POOLS * PATH_POOL_STRIDE * sizeof(uint32_t); }
 #endif
+// Exhaustive comparison of rcp_ieee / sqrt_ieee with the compiler's correctly rounded sequences: op 0: 1/x, op 1: sqrt(x),
+// over all 2^32 bit patterns.  out[0] = number of inputs whose results differ in any bit (NaN results compare equal to
+// NaN results), out[1] = the first such input found.
+namespace {
+__global__ __launch_bounds__(256) void math_check_kernel(int op, unsigned long long *out) {
+    const uint32_t base = (blockIdx.x * 256u + threadIdx.x) * 256u;
+    uint32_t bad = 0, first = 0;
+    for (uint32_t k = 0; k < 256u; k++) {
+        const float x = u2f(base + k);
+        const float a = op == 0 ? rcp_ieee(x) : sqrt_ieee(x), b = op == 0 ? rcp_slow(x) : sqrt_slow(x);
+        const bool same = (a != a && b != b) || f2u(a) == f2u(b);
+        if (!same) { if (!bad) first = base + k; bad++; }
+    }
+    if (bad) { atomicAdd(&out[0], (unsigned long long)bad); atomicMax(&out[1], (unsigned long long)first); }
+}
+}  // namespace
+int rt_math_check(int op, unsigned long long out[2]) {
+    unsigned long long *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, 16);
+    if (e == hipSuccess) e = hipMemset(d, 0, 16);
+    if (e == hipSuccess) { hipLaunchKernelGGL(math_check_kernel, dim3(1u << 16), dim3(256), 0, nullptr, op, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(out, d, 16, hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);
+    return (int)e;
+}
+
 size_t rt_render_units(uint32_t width, uint32_t n_local_rows) {
     return (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u) * (256u / RENDER_BLOCK);
 }

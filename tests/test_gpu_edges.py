@@ -187,3 +187,14 @@ def test_scene_lifecycle_returns_its_device_memory(bunny_octree, test_sky):
         if it == 2:
             base = free_bytes()
     assert abs(base - free_bytes()) < (32 << 20)
+
+
+@pytest.mark.parametrize("op,name", [(0, "1/x"), (1, "sqrt")])
+def test_short_reciprocal_and_square_root_are_correctly_rounded_for_every_input(op, name):
+    """The kernels compute 1/x and sqrt(x) as the hardware approximation plus one fused Newton step instead of the compiler's
+    long correctly rounded sequences; the library compares the two on the device for all 2^32 bit patterns of x (under
+    the kernels' arithmetic mode: denormals flushed) and must find no difference."""
+    import ctypes as C
+    out = (C.c_ulonglong * 2)()
+    assert api.lib().rt_internal_math_check(op, out) == api.RT_OK
+    assert out[0] == 0, f"{name}: {out[0]} inputs differ, e.g. bits 0x{out[1]:08x}"
