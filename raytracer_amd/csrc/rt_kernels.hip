@@ -791,7 +791,10 @@ DEVI float first_hit_depth(const rt_uniforms &U, const Hit &h, const Ray &ray) {
 }
 
 // One iteration of the path loop after the intersection (frag:583-659) for a hit: updates ray, colour and seed.
-DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed &seed) {
+// `last`: this was the path's final segment (frag:571: the loop ends), so the outgoing ray and the seed are never used
+// again and only the colour is updated -- the same colour: which factor applies depends on one random number drawn before
+// the direction is sampled.
+DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed &seed, bool last) {
     if (h.portal_id != 0) {
         const bool one = h.portal_id == 1;
         const f3 pp1 = F3(U.portal_position_1[0], U.portal_position_1[1], U.portal_position_1[2]);
@@ -801,6 +804,7 @@ DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed 
         const f3 pd = one ? pd1 : pd2, psrc = one ? pp1 : pp2, pdst = one ? pp2 : pp1;
         const float *PM = one ? U.portal_1_to_2 : U.portal_2_to_1;
         color = color * (dot3(ray.dir, pd) < 0.0f ? 0.5f : 0.05f);
+        if (last) return;
         ray.pos = mat_point(PM, h.position - psrc) + pdst;
         ray.dir = normalize3(mat_dir(PM, ray.dir));
         ray.pos = ray.pos + ray.dir * 0.001f;
@@ -809,18 +813,19 @@ DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed 
         const f3 mcol = F3(m.r, m.g, m.b);
         if (m.type == LAMBERTIAN) {
             const float F = fresnel_schlick_roughness(fmaxf(-dot3(ray.dir, h.normal), 0.0f), 0.04f, m.roughness);
+            const bool diffuse = hash1(seed) > F;
+            if (diffuse) color = color * mcol;
+            if (last) return;
             ray.pos = h.position + h.normal * 0.001f;
-            if (hash1(seed) > F) {
-                color = color * mcol;
-                ray.dir = random_cos_weighted_hemisphere_direction(h.normal, seed);
-            } else {
-                ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
-            }
+            if (diffuse) ray.dir = random_cos_weighted_hemisphere_direction(h.normal, seed);
+            else ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
         } else if (m.type == METAL) {
+            color = color * mcol;
+            if (last) return;
             ray.pos = h.position + h.normal * 0.001f;
             ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
-            color = color * mcol;
         } else {
+            if (last) return;       // a dielectric leaves the colour alone
             float ri, cosine; f3 on;
             const float dn = dot3(ray.dir, h.normal);
             if (dn > 0.0f) {
@@ -1063,8 +1068,9 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
                 }
             }
             if (!h.has_hit) { color = color * sample_sky(S, ray.dir); break; }
-            scatter(U, h, ray, color, seed);
-            ray.inv = rcp3(ray.dir);
+            const bool last = i + 1u == U.max_recursion_limit;
+            scatter(U, h, ray, color, seed, last);
+            if (!last) ray.inv = rcp3(ray.dir);
         }
         out = tonemap(color);
         if (!BATCH) write_pixel(L, p.pi, out);
@@ -1365,8 +1371,8 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
                     color = color * sample_sky(S, ray.dir);
                     done = true;
                 } else {
-                    scatter(L.u, h, ray, color, seed);
                     done = depth + 1u >= L.u.max_recursion_limit;
+                    scatter(L.u, h, ray, color, seed, done);
                 }
                 if (done) {
                     write_pixel(L, pix, tonemap(color));
@@ -1492,9 +1498,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                     color = color * sample_sky(S, ray.dir);
                     done = true;
                 } else {
-                    scatter(L.u, h, ray, color, seed);
-                    ray.inv = rcp3(ray.dir);
                     done = seg >= limit;
+                    scatter(L.u, h, ray, color, seed, done);
+                    if (!done) ray.inv = rcp3(ray.dir);
                 }
                 if (done) {
                     write_pixel(L, pix, tonemap(color));
