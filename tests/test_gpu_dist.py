@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, w=320, h=200, rows=16):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -25,7 +25,6 @@ def _worker(rank, world, port, q):
     arrays = rdist.broadcast_scene(arrays, dev)
     sc = api.Scene.from_dict(arrays, device=0)
     sc.set_skybox(arrays["sky"])
-    w, h, rows = 320, 200, 16
     us = [Uniforms.from_camera(Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=w / h), time=k / 60.0).pack() for k in range(2)]
     band = torch.zeros((rdist.padded_row_count(h, rows, world), w, 4), dtype=torch.float32, device=dev)
     g = rdist.FrameGatherer(h, rows)
@@ -49,15 +48,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_bands_gathered_equal_single_rank_frame():
+@pytest.mark.parametrize("world,size,rows", [(2, (320, 200), 16), (3, (250, 100), 8)])   # ragged: 12.5 strips for 2 ranks, 12.5 for 3
+def test_ranks_bands_gathered_equal_single_rank_frame(world, size, rows):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 200
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + (os.getpid() + 7 * world) % 200
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, size[0], size[1], rows)) for r in range(world)]
     for p in ps:
         p.start()
     res = dict(q.get(timeout=240) for _ in ps)
     for p in ps:
         p.join(60)
-    assert res == {0: True, 1: True}
+    assert res == {r: True for r in range(world)}
