@@ -628,7 +628,11 @@ DEVI void stage_portals(PortalBasis *lds2, const rt_uniforms &U) {
 DEVI float ray_portal(const Ray &r, f3 ppos, f3 pn, const PortalBasis &pb, float pw, float ph, float closest) {
     const float d = dot3(pn, r.dir);
     if (__builtin_fabsf(d) <= 0.0001f) return __builtin_inff();
-    const float t = div_ieee(dot3(ppos - r.pos, pn), d);
+    const float num = dot3(ppos - r.pos, pn);
+    // The plane behind the ray: t = num / d is negative -- and a normal number, not flushed to -0 -- whenever the signs
+    // differ and |num| >= |d| * 2^-100, so the quotient need not be formed to know that `t < 0` rejects (NaNs fall through).
+    if ((num < 0.0f) != (d < 0.0f) && __builtin_fabsf(num) >= __builtin_fabsf(d) * 0x1p-100f) return __builtin_inff();
+    const float t = div_ieee(num, d);
     if (t < 0.0f || t > closest) return __builtin_inff();
     const f3 ip = r.pos + r.dir * t;
     if (!pb.ok) return __builtin_inff();
