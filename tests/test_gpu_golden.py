@@ -89,3 +89,27 @@ def test_hip_matches_llvmpipe_with_rasteriser_ndc(gpu_scene):
     nx, ny = apply_ulp_delta(cx, z["ndc_dx"]), apply_ulp_delta(cy, z["ndc_dy"])
     gpu_scene.set_skybox(z["sky"])
     check(gpu_scene.render(z["uniforms"], w, h, ndc=(nx, ny)), z, tuple(int(v) for v in z["rows"]))
+
+
+def test_hip_sequence_matches_llvmpipe_accumulation(bunny_octree):
+    """The four accumulated reference frames again, issued as ONE rt_render_sequence call into device memory: the frames
+    are traced by one launch and blended inside the kernel, and must still equal what llvmpipe's blend unit produced."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "ref_accum.npz"))
+    w, h = (int(v) for v in z["size"])
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(z["sky"])
+    sc.set_pipeline("megakernel")
+    frames = []
+    for k, t in enumerate(z["times"]):
+        u = z["uniforms"].copy()
+        u[20] = t
+        frames.append(api.make_frame(u, w, h, accum_index=k + 1))
+    for max_batch in (0, 1, 2):          # the library's choice (all four in one launch), no batching, pairs
+        sc.set_sequence_batch(max_batch)
+        color = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        tg = api.rt_target()
+        tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 1, color.data_ptr()
+        sc.render_sequence_raw(frames, tg)
+        assert np.array_equal(bits(color.cpu().numpy()), bits(z["rgba"])), max_batch
+    sc.close()
