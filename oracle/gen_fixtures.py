@@ -11,7 +11,7 @@ Fixtures
                           primary hit (kind, triangle-reference slot / sphere index, t), segment count and final RNG seed
   ref_math.npz            llvmpipe's sin/cos/pow and cubemap lookups on probe inputs (own probe shader text)
   ref_sky_sizes.npz       cubemap lookups at face sizes 9, 30 and 100 (own probe shader text)
-  ref_accum.npz           4 progressively blended frames (time varies), final colour
+  ref_accum.npz           4 progressively blended frames (time varies), final colour; ref_accum8.npz: 8 frames
   refscene_<name>.npz     the same record for scenes other than the bunny, stored WITH their scene arrays (vertices, normals,
                           triangle references, node words, bounds): a cluster of small meshes carrying all seven materials
                           on triangles, and the reference's quad mesh assets/suzanne.obj (as triangulated by oracle.parse_obj)
@@ -234,7 +234,22 @@ def sky_size_fixture():
     print("sky sizes", os.path.getsize(os.path.join(GOLDEN, "ref_sky_sizes.npz")))
 
 
+def accum8_fixture():
+    """ref_accum8.npz: eight progressively blended frames (the blend factors 1/1 .. 1/8), 96 x 64."""
+    scene, sky = bunny_scene(), fixture_sky()
+    times = (np.arange(8, dtype=np.float32) / np.float32(60.0)).astype(np.float32)
+    u = Uniforms.from_camera(Camera(aspect=1.5), max_recursion_limit=3).pack()
+    acc = refrun.run_reference(scene, u, 128, 64, sky=sky, times=times)
+    np.savez_compressed(os.path.join(GOLDEN, "ref_accum8.npz"), uniforms=u, sky=sky, size=np.array([128, 64], np.int32), times=times, rgba=acc["rgba"])
+    print("accum8", os.path.getsize(os.path.join(GOLDEN, "ref_accum8.npz")))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "accum8":
+        refrun.build()
+        assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+        accum8_fixture()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sky":
         refrun.build()
         assert refrun.available(), "needs /root/reference and the llvmpipe runner"
@@ -290,6 +305,7 @@ def main():
     print("ndc 640x512: x differs on %.1f%% of pixels, y on %.1f%%" % (100 * (dx != 0).mean(), 100 * (dy != 0).mean()))
     scene_fixtures()
     sky_size_fixture()
+    accum8_fixture()
     total = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
     print("fixtures total bytes:", total)
 

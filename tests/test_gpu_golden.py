@@ -13,7 +13,7 @@ from raytracer_amd import api
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_math.npz", "ref_ndc_640x512.npz", "ref_sky_sizes.npz"))
+VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_accum8.npz", "ref_math.npz", "ref_ndc_640x512.npz", "ref_sky_sizes.npz"))
 
 
 def bits(a):
@@ -112,4 +112,27 @@ def test_hip_sequence_matches_llvmpipe_accumulation(bunny_octree):
         tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 1, color.data_ptr()
         sc.render_sequence_raw(frames, tg)
         assert np.array_equal(bits(color.cpu().numpy()), bits(z["rgba"])), max_batch
+    sc.close()
+
+
+@pytest.mark.parametrize("pipeline", ["megakernel", "wavefront", "persistent"])
+def test_hip_sequence_matches_llvmpipe_eight_frame_accumulation(bunny_octree, pipeline):
+    """Eight accumulated reference frames as one sequence call: the one-lane-per-pixel kernel traces them in one launch, in two
+    groups of four waves whose samples go through the staging plane and blend_batch_kernel."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "ref_accum8.npz"))
+    w, h = (int(v) for v in z["size"])
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(z["sky"])
+    sc.set_pipeline(pipeline)
+    frames = []
+    for k, t in enumerate(z["times"]):
+        u = z["uniforms"].copy()
+        u[20] = t
+        frames.append(api.make_frame(u, w, h, accum_index=k + 1))
+    color = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    tg = api.rt_target()
+    tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 1, color.data_ptr()
+    sc.render_sequence_raw(frames, tg)
+    assert np.array_equal(bits(color.cpu().numpy()), bits(z["rgba"]))
     sc.close()

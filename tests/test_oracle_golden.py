@@ -12,7 +12,7 @@ from oracle import oracle
 from oracle.gen_fixtures import apply_ulp_delta, closed_form_ndc, bunny_scene
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_math.npz", "ref_ndc_640x512.npz", "ref_sky_sizes.npz"))
+VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_accum8.npz", "ref_math.npz", "ref_ndc_640x512.npz", "ref_sky_sizes.npz"))
 
 
 def bits(a):
@@ -137,3 +137,15 @@ def test_oracle_cubemap_at_other_face_sizes(size):
     empty = dict(vertices=np.zeros((1, 4)), normals=np.zeros((1, 4)), tri_refs=np.zeros((1, 4)), nodes=np.zeros(0), bounds_min=[0, 0, 0], bounds_max=[0, 0, 0])
     o = oracle.OracleScene(empty, z[f"sky_{size}"]).sample_sky(z["dirs"])
     assert np.array_equal(bits(o), bits(z[f"rgb_{size}"]))
+
+
+def test_oracle_eight_frame_accumulation(scene):
+    z = np.load(os.path.join(GOLDEN, "ref_accum8.npz"))
+    w, h = (int(v) for v in z["size"])
+    osc = oracle.OracleScene(scene, z["sky"])
+    acc = None
+    for k, t in enumerate(z["times"]):
+        u = z["uniforms"].copy()
+        u[20] = t
+        acc = osc.render(u, w, h, accum_index=k + 1, rgba=acc, taps=False)["rgba"]
+    assert np.array_equal(bits(acc), bits(z["rgba"]))
