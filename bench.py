@@ -83,6 +83,8 @@ def main():
                     help="N > 1: the accumulated frame is gathered to rank 0 after every this many steps and after the last one. "
                          "0 = 16 x N: a step takes about 0.67 ms / N, so the frame is presented about 100 times a second whatever N is "
                          "(a 4K RGBA32F frame is 132.7 MB: gathered after every step it would measure the xGMI links, not the renderer)")
+    ap.add_argument("--traversal", default="reference", choices=["reference", "near_first"],
+                    help="child order of the octree traversal: the shader's own (bit-identical results) or nearest first (faster; colour tolerance only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,6 +137,7 @@ def main():
     sc = api.Scene.from_dict(scene_arrays, device=local_rank)
     sc.set_skybox(sky)
     sc.set_pipeline(args.pipeline)
+    sc.set_traversal_order(args.traversal)
     if args.subframes:
         sc.set_subframes(args.subframes)
     t_build = time.time() - t_build
@@ -249,13 +252,14 @@ def main():
         "scene_build_s": round(t_build, 3),
     }
     out["config"]["pipeline"] = pipeline + (" (selected by the library: measured ms/frame %s)" % {k: (round(v, 3) if v is not None else None) for k, v in pipeline_ms.items()} if args.pipeline == "auto" else "")
+    out["config"]["traversal_order"] = args.traversal + (" (bit-identical to the reference shader)" if args.traversal == "reference" else " (not the reference's order: colour tolerance only)")
     out["config"]["issue"] = ("rt_render_sequence over the K steps" if world == 1 else f"rt_render_sequence per {present_every} steps") if sequence else "one rt_render per step"
     # ---- roofline of the dominant kernel, this rank's launches --------------------------------------------------
     kernel = {"wavefront": "traverse_kernel", "megakernel": "render_kernel", "persistent": "path_kernel"}[pipeline]
     if pipeline == "megakernel" and k_launches < args.steps:
         kernel = "render_batch_kernel"   # the library traced several frames of the sequence per launch
     k_ms = k_total_ms / max(k_launches, 1)
-    default_workload = world == 1 and args.scene == "bunny" and (W, H, args.max_recursion_limit) == (3840, 2160, 2)
+    default_workload = world == 1 and args.scene == "bunny" and (W, H, args.max_recursion_limit) == (3840, 2160, 2) and args.traversal == "reference"
     px_local = W * min(rows_local, H) if parts > 1 else W * H
     local_work = {k: v for k, v in local_tot.items()}
     total_bytes = traversal_bytes(local_work) if pipeline == "wavefront" else frame_bytes(local_work, px_local * args.steps, blended=True)

@@ -173,6 +173,18 @@ int rt_scene_set_subframes(rt_scene *scene, int n);
  * are independent -- and blended into the target in frame order by a second small kernel; the pixels are the same.
  * 0 (default): chosen from the size of the launch; 1: never. */
 int rt_scene_set_sequence_batch(rt_scene *scene, int max_frames);
+/* Order in which the children of an octree node are visited (no counterpart in the reference, whose order is fixed).
+ * RT_ORDER_REFERENCE (default): the shader's own -- passing children in descending octant order whatever the ray's
+ * direction (frag:489-513) -- with which every output is bit-identical to the shader's.
+ * RT_ORDER_NEAR_FIRST: the children on the ray's near side first.  Closer hits are found earlier, later box tests reject
+ * more (5 % fewer node visits on the reference's scene, 60 % on a scene of 1.6 M triangles) and frames get faster.  The
+ * closest hit is searched over a different set of nodes, so a result can differ from the shader's where floating-point
+ * box and triangle tests disagree about a hit on a box boundary, and where two references or two triangles give exactly
+ * the same distance the other one may be reported (same distance, the same triangle when the references are duplicates).
+ * This mode is held to the tolerance bar -- colour within 1/255 on at least 99.9 % of the pixels -- not to bit identity. */
+#define RT_ORDER_REFERENCE 0
+#define RT_ORDER_NEAR_FIRST 1
+int rt_scene_set_traversal_order(rt_scene *scene, int order);
 int rt_scene_destroy(rt_scene *scene);
 
 /* Host-side scene build: mirrors of the reference's Mesh and Octree classes --------------------------------- */

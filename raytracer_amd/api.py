@@ -29,7 +29,7 @@ HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = r
 
 EXPORTED_SYMBOLS = [
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_band_row_count", "rt_scene_stats",
-    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free",
+    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free",
 ]
 
 
@@ -104,6 +104,7 @@ def lib():
         L.rt_scene_pipeline_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.rt_scene_set_subframes.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_set_sequence_batch.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_set_traversal_order.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_mesh_load_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
         L.rt_mesh_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
@@ -267,6 +268,10 @@ class Scene:
 
     def set_sequence_batch(self, max_frames: int):
         _check(lib().rt_scene_set_sequence_batch(self._h, max_frames))
+
+    def set_traversal_order(self, order: str):
+        """'reference' (default: bit-identical to the shader) or 'near_first' (faster, held to the colour tolerance only)."""
+        _check(lib().rt_scene_set_traversal_order(self._h, {"reference": 0, "near_first": 1}[order]))
 
     def set_subframes(self, n: int):
         _check(lib().rt_scene_set_subframes(self._h, n))

@@ -70,6 +70,7 @@ struct rt_scene {
     void *stage = nullptr;      // sample staging of batched sequence launches (RtBatch)
     size_t stage_elems = 0;
     int max_batch = 0;          // 0: automatic; 1: never batch
+    int order = RT_ORDER_REFERENCE;
     // RT_PIPELINE_AUTO: the three pipelines give identical pixels, so the scene measures them on its own frames (event
     // pairs around a call's launches, read back without blocking at a later call) and uses the fastest for the workload
     // at hand; the others are measured again now and then.
@@ -336,6 +337,13 @@ int rt_scene_pipeline_state(rt_scene *s, int *selected, double ms_per_frame[3]) 
     return RT_OK;
 }
 
+int rt_scene_set_traversal_order(rt_scene *s, int order) {
+    if (!s) return fail(RT_EINVAL, "scene is null");
+    if (order != RT_ORDER_REFERENCE && order != RT_ORDER_NEAR_FIRST) return fail(RT_EINVAL, "unknown traversal order %d", order);
+    s->order = order;
+    return RT_OK;
+}
+
 int rt_scene_set_sequence_batch(rt_scene *s, int max_frames) {
     if (!s) return fail(RT_EINVAL, "scene is null");
     if (max_frames < 0 || max_frames > RT_MAX_BATCH) return fail(RT_EINVAL, "batch must be in [0,%d]", RT_MAX_BATCH);
@@ -501,6 +509,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
     L.n_local_rows = band_rows_of(f);   // rows owned by this part: whole strips, the last one clipped by the kernel
     L.compact_rows = f->compact_rows;
+    L.near_first = s->order == RT_ORDER_NEAR_FIRST ? 1u : 0u;
     L.counters = s->counting ? s->d_counters : nullptr;
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
 
@@ -508,7 +517,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     int pipeline = s->pipeline;
     bool measure = false;
     if (pipeline == RT_PIPELINE_AUTO) {
-        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^ (uint64_t)(n_frames > 1 ? 2 : 0);
+        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^ (uint64_t)(n_frames > 1 ? 2 : 0) ^ (uint64_t)(s->order ? 4 : 0);
         pipeline = tuner_choose(s, key + 1, &measure);
     }
     const bool wavefront = pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;

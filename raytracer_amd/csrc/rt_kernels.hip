@@ -434,16 +434,17 @@ template <int STRIDE>   // threads per workgroup = distance in words between two
 struct LevelStackT {
     uint32_t *col;   // &lds[threadIdx.x]
     int sp;
-    DEVI void reset_to_root() { col[0] = 0u | (1u << 24); sp = 1; }   // the root is octant 0 of a virtual level
+    // the root is octant 0 of a virtual level; `key` is the octant permutation of this ray (0: the reference's order)
+    DEVI void reset_to_root(uint32_t key) { col[0] = 0u | ((1u << key) << 24); sp = 1; }
     DEVI bool empty() const { return sp == 0; }
-    DEVI uint32_t pop_node() {
+    DEVI uint32_t pop_node(uint32_t key) {
         const uint32_t e = col[(sp - 1) * STRIDE];
         const uint32_t mask = e >> 24;
         const uint32_t r = 31u - (uint32_t)__clz((int)mask);      // highest pending octant
         const uint32_t rest = mask & ~(1u << r);
         if (rest) col[(sp - 1) * STRIDE] = (e & 0x00FFFFFFu) | (rest << 24);
         else sp--;
-        return (e & 0x00FFFFFFu) + r;
+        return (e & 0x00FFFFFFu) + (r ^ key);
     }
     DEVI void push_level(uint32_t first_child, uint32_t octant_mask) { col[sp * STRIDE] = first_child | (octant_mask << 24); sp++; }
 };
@@ -490,13 +491,28 @@ DEVI TriData inline_triangle(const NodeData &n) {
     return d;
 }
 
+// Order in which the passing children of a node are visited.  The reference pushes them in ascending octant order and pops
+// the highest first, whatever the ray's direction (frag:489-513).  Optionally (RtLaunch::near_first) they are visited
+// nearest first: the level entry then stores the mask with bit (octant ^ key), key = ~(sign bits of the direction), so that
+// popping the highest bit yields the octant on the ray's near side first.  Closer hits are then found earlier and later
+// box tests reject more (the bunny scene: 5 % fewer visits, the 100 k scene: 60 %), but the set of triangles tested is
+// no longer the reference's, so equality of the results is no longer guaranteed bit for bit (see rt_hotpath.h).
+DEVI uint32_t order_key(const Ray &r, bool near_first) {
+    return near_first ? (((r.dir.x < 0.0f ? 1u : 0u) | (r.dir.y < 0.0f ? 2u : 0u) | (r.dir.z < 0.0f ? 4u : 0u)) ^ 7u) : 0u;
+}
+DEVI uint32_t permute_octants(uint32_t mask, uint32_t key) {      // bit o -> bit (o ^ key)
+    if (key & 1u) mask = ((mask & 0x55u) << 1) | ((mask & 0xAAu) >> 1);
+    if (key & 2u) mask = ((mask & 0x33u) << 2) | ((mask & 0xCCu) >> 2);
+    if (key & 4u) mask = ((mask & 0x0Fu) << 4) | ((mask & 0xF0u) >> 4);
+    return mask;
+}
 #ifndef TRI_BATCH
 #define TRI_BATCH 2u   // more in flight costs registers, and with them resident waves
 #endif
 // One visit (frag:456-513) by a single lane: test the node's triangles in order, then the boxes of its children.
 template <bool COUNT, class STACK>
-DEVI void visit_node(const RtDeviceScene &S, const Ray &r, STACK &st, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
-    const NodeData n = load_node(S, st.pop_node());
+DEVI void visit_node(const RtDeviceScene &S, const Ray &r, STACK &st, uint32_t key, bool near_first, float &closest, uint32_t &closest_tri, bool &tri_hit, Counters &cn) {
+    const NodeData n = load_node(S, st.pop_node(key));
     if (COUNT) { cn.pops++; cn.tri_tests += n.tri_count; cn.box_tests += __popc(n.child_mask); }
     // triangle records are fetched TRI_BATCH at a time so that their memory latencies overlap; they are tested in order
     // (the copy of a leaf's first triangle inside its node record is not used here: the extra branch per visit cost this
@@ -514,7 +530,8 @@ DEVI void visit_node(const RtDeviceScene &S, const Ray &r, STACK &st, float &clo
         }
     }
     if (n.child_mask == 0) return;
-    const uint32_t pass = child_pass_octants(r, n.lo, n.mid, n.hi, n.child_mask, closest);
+    uint32_t pass = child_pass_octants(r, n.lo, n.mid, n.hi, n.child_mask, closest);
+    if (near_first) pass = permute_octants(pass, key);      // (uniform branch)
     if (pass) st.push_level(n.first_child, pass);
 }
 
@@ -527,12 +544,13 @@ DEVI void visit_node(const RtDeviceScene &S, const Ray &r, STACK &st, float &clo
 struct Walk {
     NodeData node;            // current node: its child boxes are still to be tested while node.child_mask != 0
     uint32_t tri_i, tri_end;  // its triangles still to be tested
-    template <class STACK> DEVI void begin(STACK &st) { st.reset_to_root(); node.child_mask = 0; tri_i = tri_end = 0; }
+    uint32_t key;             // octant permutation of this ray (order_key)
+    template <class STACK> DEVI void begin(STACK &st, uint32_t k) { key = k; st.reset_to_root(k); node.child_mask = 0; tri_i = tri_end = 0; }
 };
 // Must be called by all lanes of a wave together; `active` marks the lanes with a live traversal and is cleared when a
 // lane's stack runs empty.
 template <bool COUNT, class STACK>
-DEVI void walk_step(const RtDeviceScene &S, const Ray &r, STACK &st, Walk &w, float &closest, uint32_t &closest_tri, bool &tri_hit, bool &active, Counters &cn) {
+DEVI void walk_step(const RtDeviceScene &S, const Ray &r, STACK &st, Walk &w, bool near_first, float &closest, uint32_t &closest_tri, bool &tri_hit, bool &active, Counters &cn) {
     const bool want_tri = active && w.tri_i < w.tri_end;
     const uint32_t n_tri = (uint32_t)__popcll(__ballot(want_tri)), n_pop = (uint32_t)__popcll(__ballot(active && !want_tri));
     if (n_tri != 0 && n_tri >= n_pop) {
@@ -551,14 +569,15 @@ DEVI void walk_step(const RtDeviceScene &S, const Ray &r, STACK &st, Walk &w, fl
         }
     } else if (active && !want_tri) {
         if (w.node.child_mask != 0) {
-            const uint32_t pass = child_pass_octants(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest);
+            uint32_t pass = child_pass_octants(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest);
+            if (near_first) pass = permute_octants(pass, w.key);
             if (pass) st.push_level(w.node.first_child, pass);
             w.node.child_mask = 0;
         }
         if (st.empty()) {
             active = false;
         } else {
-            w.node = load_node(S, st.pop_node());
+            w.node = load_node(S, st.pop_node(w.key));
             if (COUNT) { cn.pops++; cn.tri_tests += w.node.tri_count; cn.box_tests += __popc(w.node.child_mask); }
             w.tri_i = w.node.tri_start; w.tri_end = w.node.tri_start + w.node.tri_count;
             if (w.node.child_mask == 0 && w.node.tri_count != 0) {   // a leaf's record holds its first triangle
@@ -1056,8 +1075,10 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
             if (root_box_test(S, ray, closest)) {
                 if (COUNT) cn.entered++;
                 // (a lane per visit here: with a wave's rays this coherent the wave-wide walk_step measured 10 % slower)
-                st.reset_to_root();
-                while (!st.empty()) visit_node<COUNT>(S, ray, st, closest, closest_tri, tri_hit, cn);
+                const bool near_first = L.near_first != 0u;
+                const uint32_t key = order_key(ray, near_first);
+                st.reset_to_root(key);
+                while (!st.empty()) visit_node<COUNT>(S, ray, st, key, near_first, closest, closest_tri, tri_hit, cn);
             }
             PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
             const Hit h = finish_intersection<COUNT>(S, U, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
@@ -1285,7 +1306,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
     Walk walk;
     walk.node.tri_start = walk.node.tri_count = walk.node.child_mask = walk.node.first_child = 0;
     walk.node.lo = walk.node.mid = walk.node.hi = F3(0.0f, 0.0f, 0.0f);
-    walk.tri_i = walk.tri_end = 0;
+    walk.tri_i = walk.tri_end = 0; walk.key = 0;
     for (;;) {
         unsigned long long busy = __ballot(has);
         if (!exhausted && 64 - __popcll(busy) >= REFILL_IDLE) {
@@ -1306,7 +1327,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
                 ray.inv = rcp3(ray.dir);
                 closest = WS.t[slot];
                 closest_tri = 0; tri_hit = false;
-                walk.begin(st);
+                walk.begin(st, order_key(ray, L.near_first != 0u));
                 has = true;
                 if (COUNT) cn.entered++;
             }
@@ -1316,7 +1337,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
         }
         if (busy == 0) { if (exhausted) break; else continue; }
         const bool was = has;
-        walk_step<COUNT>(S, ray, st, walk, closest, closest_tri, tri_hit, has, cn);
+        walk_step<COUNT>(S, ray, st, walk, L.near_first != 0u, closest, closest_tri, tri_hit, has, cn);
         if (was && !has) {
             WS.t[slot] = closest;
             if (tri_hit) WS.tri[slot] = closest_tri | 0x80000000u;
@@ -1472,7 +1493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
     Walk walk;
     walk.node.tri_start = walk.node.tri_count = walk.node.child_mask = walk.node.first_child = 0;
     walk.node.lo = walk.node.mid = walk.node.hi = F3(0.0f, 0.0f, 0.0f);
-    walk.tri_i = walk.tri_end = 0;
+    walk.tri_i = walk.tri_end = 0; walk.key = 0;
     uint32_t pix = 0, seg = 0, closest_i = 0, closest_tri = 0;
     float closest = 0.0f;
     Ray ray;
@@ -1549,7 +1570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                 SPHERE_LOOP(false, lds_sph, ray, closest, closest_i);
                 if (root_box_test(S, ray, closest)) {
                     if (COUNT) cn.entered++;
-                    walk.begin(st);
+                    walk.begin(st, order_key(ray, L.near_first != 0u));
                     traversing = true;
                 }
             }
@@ -1561,7 +1582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                 const unsigned long long w = __ballot(!traversing && (has_path || unit < n_units));
                 if ((uint32_t)__popcll(w) >= (unit < n_units ? PATH_REFILL : 1u)) break;
             }
-            walk_step<COUNT>(S, ray, st, walk, closest, closest_tri, tri_hit, traversing, cn);
+            walk_step<COUNT>(S, ray, st, walk, L.near_first != 0u, closest, closest_tri, tri_hit, traversing, cn);
         }
     }
 #ifdef PATH_TRACE   // development aid: per-wave start / end wall clock behind the counters

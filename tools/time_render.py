@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--pipelines", default="wavefront,megakernel")
     ap.add_argument("--subframes", default="4", help="comma list of sub-frame counts")
+    ap.add_argument("--order", default="reference", choices=["reference", "near_first"])
     ap.add_argument("--host", action="store_true", help="host-memory target: every frame is staged over PCIe")
     ap.add_argument("--sequence", action="store_true", help="issue the timed frames as one rt_render_sequence call")
     a = ap.parse_args()
@@ -31,7 +32,7 @@ def main():
         d = empty_scene() if name == "empty" else {"bunny": scenes.default_octree, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "small": scenes.small_test_scene}[name]().as_dict()
         sc = api.Scene.from_dict(d); sc.set_skybox(sky)
         for pipe, lim, sub in [(p, int(x), int(k)) for p in a.pipelines.split(",") for x in a.limits.split(",") for k in a.subframes.split(",")]:
-            sc.set_pipeline(pipe); sc.set_subframes(sub)
+            sc.set_pipeline(pipe); sc.set_subframes(sub); sc.set_traversal_order(a.order)
             host_color = np.zeros((H, W, 4), np.float32)
             def run(k, sync=False):
                 if a.host:
