@@ -272,6 +272,9 @@ def main():
                        "device_rate": {"what": "algorithmic bytes of this kernel per frame / frame time (its launches of one frame run concurrently on separate streams)",
                                        "GB/s": round(total_bytes / max(k_launches, 1) * (k_launches / args.steps) / (1e6 * 1e3 * elapsed / args.steps), 3)},
                        "note": "octree traversal is bound by dependent-load latency and VALU issue, not by HBM bandwidth: see the valu object"}
+    if achieved > HBM_PEAK_GBS:
+        out["roofline"]["note"] += ("; frac > 1 here: the per-ray byte count prices every node and triangle record a ray touches as a memory read, and on this "
+                                    "workload most of them are served by the caches, so the count is no lower bound on HBM bytes")
     aflops = algorithmic_flops(local_work) / args.steps
     frame_ms = 1e3 * elapsed / args.steps
     out["valu"] = {"scope": "whole frame" if world == 1 else "rank 0's share of the frame", "achieved_tflops": round(aflops / (frame_ms * 1e-3) / 1e12, 3), "peak_tflops_no_fma": VALU_PEAK_TFLOPS_NO_FMA,

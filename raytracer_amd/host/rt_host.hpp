@@ -122,6 +122,9 @@ public:
     // App.cpp:90-92,209: any camera change or resize restarts the accumulation.
     void ResetAccumulation() { m_still_frame_counter = 1; }
     uint32_t StillFrameCounter() const { return m_still_frame_counter; }
+    // No counterpart in the reference: visit octree children nearest first (faster on deep scenes; outside bit
+    // parity with the shader, whose fixed octant order is the default).
+    void SetNearFirstTraversal(bool on) { check(rt_scene_set_traversal_order(m_scene, on ? RT_ORDER_NEAR_FIRST : RT_ORDER_REFERENCE)); }
 
     // App::Render's ray-tracing draw (App.cpp:97-140) into device memory; sync = false returns after the enqueue.
     void Render(const rt_uniforms &u, uint32_t width, uint32_t height, float *color_dev, float *depth_dev = nullptr, void *stream = nullptr, bool sync = false) {
