@@ -4,7 +4,10 @@
 // mesh.bin: u32 n_vert, u32 n_face, f32 pos[n_vert][3], u32 face[n_face][3]
 // out.bin:  u64 n_vert, n_ref, n_words, f32 min[3], max[3], then vertices, normals, tri refs, node words;
 //           with rendering: f32 rgba[height][width][4] and f32 depth[height][width] after n_frames accumulated draws
-// uniforms.bin: n_frames x 70 words (rt_uniforms)
+// uniforms.bin: n_frames x 70 words (rt_uniforms); the literal word `walk` instead of a file name makes the demo play the
+//           reference's interactive loop itself: default view and portals (App.cpp:31-34,58-61), the W key held for all
+//           but the last two frames at 1/60 s per frame (CameraManipulator::Update), accumulation restarted whenever the
+//           view changed (App.cpp:90-92); the uniforms it used are appended to out.bin (n_frames x 70 words)
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime_api.h>
@@ -35,19 +38,39 @@ int main(int argc, char **argv) {
         put(out, octree.m_compressed_triangles.data(), sizes[1] * 16); put(out, octree.m_compressed_node_buffer.data(), sizes[2] * 4);
         if (argc == 7) {
             const uint32_t w = (uint32_t)atoi(argv[4]), h = (uint32_t)atoi(argv[5]), n = (uint32_t)atoi(argv[6]);
+            const bool walk = std::string(argv[3]) == "walk";
             std::vector<rt_uniforms> u(n);
-            FILE *uf = fopen(argv[3], "rb");
-            if (!uf || fread(u.data(), sizeof(rt_uniforms), n, uf) != n) { fprintf(stderr, "cannot read uniforms\n"); return 2; }
-            fclose(uf);
+            if (!walk) {
+                FILE *uf = fopen(argv[3], "rb");
+                if (!uf || fread(u.data(), sizeof(rt_uniforms), n, uf) != n) { fprintf(stderr, "cannot read uniforms\n"); return 2; }
+                fclose(uf);
+            }
             float *color = nullptr, *depth = nullptr;
             if (hipMalloc((void **)&color, (size_t)w * h * 16) != hipSuccess || hipMalloc((void **)&depth, (size_t)w * h * 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 3; }
             (void)hipMemset(color, 0, (size_t)w * h * 16);
             rt::RayTracePass pass(octree);
-            pass.Render(u[0], w, h, color, depth, nullptr, true);                       // one draw ...
-            if (n > 1) pass.RenderFrames(std::vector<rt_uniforms>(u.begin() + 1, u.end()), w, h, color, depth, nullptr, true);   // ... then the rest as a sequence
+            if (walk) {
+                rt::Camera camera;
+                camera.SetView({2, 2, 2}, {0, 0, 0}, {0, 1, 0});
+                camera.SetAspect((float)w / (float)h);
+                rt::CameraManipulator manipulator;
+                manipulator.SetCamera(&camera);
+                const rt::Portal portal_1({7.0f, 2.5f, 1.0f}, rt::normalize({2.0f, 0.0f, 0.5f})), portal_2({7.0f, 1.5f, 5.0f}, rt::normalize({0.0f, 0.0f, 1.0f}));
+                manipulator.KeyboardDown(RT_KEY_W);
+                for (uint32_t k = 0; k < n; ++k) {
+                    if (k + 2 == n) manipulator.KeyboardUp(RT_KEY_W);
+                    if (manipulator.Update(1.0f / 60.0f, portal_1, portal_2, 2.0f, 3.0f)) pass.ResetAccumulation();
+                    u[k] = rt::FrameUniforms(camera, portal_1, portal_2, 2.0f, 3.0f, (float)k / 60.0f);
+                    pass.Render(u[k], w, h, color, depth, nullptr, true);
+                }
+            } else {
+                pass.Render(u[0], w, h, color, depth, nullptr, true);                       // one draw ...
+                if (n > 1) pass.RenderFrames(std::vector<rt_uniforms>(u.begin() + 1, u.end()), w, h, color, depth, nullptr, true);   // ... then the rest as a sequence
+            }
             std::vector<float> hc((size_t)w * h * 4), hd((size_t)w * h);
             if (hipMemcpy(hc.data(), color, hc.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hd.data(), depth, hd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return 3;
             put(out, hc.data(), hc.size() * 4); put(out, hd.data(), hd.size() * 4);
+            if (walk) put(out, u.data(), u.size() * sizeof(rt_uniforms));
             (void)hipFree(color); (void)hipFree(depth);
         }
         fclose(out);

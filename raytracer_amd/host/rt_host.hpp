@@ -6,6 +6,8 @@
 //   RayTracePass replaces what App keeps for the ray-tracing draw: the four storage buffers (App.cpp:23-26), the
 //               skybox texture (Skybox.cpp:46-57), the accumulation counter (App.cpp:29,90-92,104-105,209) and the
 //               draw itself (App.cpp:107-140)
+//   Camera, Portal, CameraManipulator mirror the classes of the same names (Camera.hpp:5-56, Portal.hpp,
+//               CameraManipulator.hpp:12-65) on include/rt_camera.h: binary32 arithmetic in glm's operation order
 //
 // Errors are reported as rt::Error exceptions carrying the ABI's status code and message; the reference logs and
 // exits (Mesh.cpp:20-26) or logs and continues (GL).
@@ -16,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/rt_camera.h"
 #include "../../include/rt_hotpath.h"
 
 namespace rt {
@@ -159,5 +162,83 @@ private:
     rt_scene *m_scene = nullptr;
     uint32_t m_still_frame_counter = 1;            // App.cpp:29
 };
+
+// Camera.hpp:5-56.
+class Camera {
+public:
+    Camera() { rt_camera_init(&m_c); }
+    vec3 GetEye() const { return {m_c.eye[0], m_c.eye[1], m_c.eye[2]}; }
+    vec3 GetAt() const { return {m_c.at[0], m_c.at[1], m_c.at[2]}; }
+    vec3 GetWorldUp() const { return {m_c.world_up[0], m_c.world_up[1], m_c.world_up[2]}; }
+    mat4 GetViewMatrix() const { mat4 r; std::memcpy(r.m, m_c.view, sizeof r.m); return r; }
+    mat4 GetProj() const { mat4 r; std::memcpy(r.m, m_c.proj, sizeof r.m); return r; }
+    mat4 GetViewProj() const { mat4 r; rt_camera_view_proj(&m_c, r.m); return r; }
+    void SetView(vec3 eye, vec3 at, vec3 up) { rt_camera_set_view(&m_c, &eye.x, &at.x, &up.x); }
+    void SetProj(float angle, float aspect, float zn, float zf) { rt_camera_set_proj(&m_c, angle, aspect, zn, zf); }
+    float GetAngle() const { return m_c.angle; }
+    void SetAngle(float a) { SetProj(a, m_c.aspect, m_c.z_near, m_c.z_far); }
+    float GetAspect() const { return m_c.aspect; }
+    void SetAspect(float a) { SetProj(m_c.angle, a, m_c.z_near, m_c.z_far); }
+    float GetZNear() const { return m_c.z_near; }
+    void SetZNear(float zn) { SetProj(m_c.angle, m_c.aspect, zn, m_c.z_far); }
+    float GetZFar() const { return m_c.z_far; }
+    void SetZFar(float zf) { SetProj(m_c.angle, m_c.aspect, m_c.z_near, zf); }
+    rt_camera *Handle() { return &m_c; }
+    const rt_camera *Handle() const { return &m_c; }
+private:
+    rt_camera m_c;
+};
+
+inline vec3 normalize(vec3 v) { vec3 r; rt_vec3_normalize(&v.x, &r.x); return r; }   // glm::normalize
+
+// Portal.hpp / Portal.cpp:3-58.
+class Portal {
+public:
+    Portal(vec3 position, vec3 direction) : m_position(position), m_direction(direction) {}
+    vec3 GetPosition() const { return m_position; }
+    vec3 GetDirection() const { return m_direction; }
+    mat4 GetDifferenceMatrixTo(const Portal &destination_portal) const {
+        mat4 r;
+        rt_portal_difference_matrix(&m_direction.x, &destination_portal.m_direction.x, r.m);
+        return r;
+    }
+    float RayPortal(vec3 ray_position, vec3 ray_direction, float closest_distance, float portal_width, float portal_height) const {
+        return rt_portal_ray(&m_position.x, &m_direction.x, &ray_position.x, &ray_direction.x, closest_distance, portal_width, portal_height);
+    }
+private:
+    vec3 m_position, m_direction;
+};
+
+// CameraManipulator.hpp:12-65; events arrive as plain numbers (key = RT_KEY_*).
+class CameraManipulator {
+public:
+    CameraManipulator() { rt_manipulator_init(&m_m); }
+    void SetCamera(Camera *camera) { m_pCamera = camera; if (camera) rt_manipulator_set_camera(&m_m, camera->Handle()); }
+    bool Update(float delta_time, const Portal &portal_1, const Portal &portal_2, float portal_width, float portal_height) {
+        if (!m_pCamera) return false;
+        const vec3 p1 = portal_1.GetPosition(), d1 = portal_1.GetDirection(), p2 = portal_2.GetPosition(), d2 = portal_2.GetDirection();
+        return rt_manipulator_update(&m_m, m_pCamera->Handle(), delta_time, &p1.x, &d1.x, &p2.x, &d2.x, portal_width, portal_height) != 0;
+    }
+    void SetSpeed(float speed) { m_m.speed = speed; }
+    float GetSpeed() const { return m_m.speed; }
+    void KeyboardDown(int key, int repeat = 0) { rt_manipulator_key(&m_m, key, 1, repeat); }
+    void KeyboardUp(int key) { rt_manipulator_key(&m_m, key, 0, 0); }
+    void MouseMove(int xrel, int yrel, bool left, bool right) { rt_manipulator_mouse_move(&m_m, left, right, xrel, yrel); }
+    void MouseWheel(int y) { rt_manipulator_mouse_wheel(&m_m, y); }
+private:
+    Camera *m_pCamera = nullptr;
+    rt_manipulator m_m;
+};
+
+// The uniforms of one draw as App::Render uploads them (App.cpp:120-138).
+inline rt_uniforms FrameUniforms(const Camera &camera, const Portal &portal_1, const Portal &portal_2, float portal_width, float portal_height,
+                                 float time, uint32_t max_recursion_limit = 5, float blur_amount = 0.00001f) {
+    rt_uniforms u{};
+    rt_uniforms_set_camera(&u, camera.Handle());
+    const vec3 p1 = portal_1.GetPosition(), d1 = portal_1.GetDirection(), p2 = portal_2.GetPosition(), d2 = portal_2.GetDirection();
+    rt_uniforms_set_portals(&u, &p1.x, &d1.x, &p2.x, &d2.x, portal_width, portal_height);
+    u.time = time; u.max_recursion_limit = max_recursion_limit; u.blur_amount = blur_amount;
+    return u;
+}
 
 }  // namespace rt

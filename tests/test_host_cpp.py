@@ -28,7 +28,10 @@ def _run_demo(tmp_path, pos, faces, render=None):
     with open(mesh_bin, "wb") as f:
         f.write(np.array([len(pos), len(faces)], np.uint32).tobytes()); f.write(pos.tobytes()); f.write(faces.tobytes())
     cmd = [DEMO, str(mesh_bin), str(out_bin)]
-    if render:
+    walk = bool(render) and render[0] == "walk"
+    if walk:
+        cmd += ["walk", str(render[1]), str(render[2]), str(render[3])]
+    elif render:
         us, w, h = render
         (tmp_path / "u.bin").write_bytes(np.concatenate(us).astype(np.float32).tobytes())
         cmd += [str(tmp_path / "u.bin"), str(w), str(h), str(len(us))]
@@ -44,8 +47,10 @@ def _run_demo(tmp_path, pos, faces, render=None):
     d = dict(bounds_min=take(np.float32, 3), bounds_max=take(np.float32, 3), vertices=take(np.float32, nv * 4).reshape(-1, 4), normals=take(np.float32, nv * 4).reshape(-1, 4),
              tri_refs=take(np.uint32, nr * 4).reshape(-1, 4), nodes=take(np.uint32, nw))
     if render:
-        us, w, h = render
+        w, h = render[1], render[2]
         d["rgba"] = take(np.float32, w * h * 4).reshape(h, w, 4); d["depth"] = take(np.float32, w * h).reshape(h, w)
+    if walk:
+        d["uniforms"] = take(np.float32, render[3] * 70).reshape(-1, 70)
     assert off == len(raw)
     return d
 
@@ -79,3 +84,42 @@ def test_cpp_render_pass_accumulates_like_scene_render(tmp_path):
     sc.close()
     assert np.array_equal(d["rgba"].view(np.uint32), acc.view(np.uint32))
     assert np.array_equal(d["depth"].view(np.uint32), depth.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_camera_walk_like_the_reference_loop(tmp_path):
+    """The demo's `walk` mode plays App's loop with the C++ Camera / CameraManipulator mirror (W held, then released for
+    the last two frames): its uniforms equal the Python mirror's walk, and the image it accumulates equals the frames of
+    the standing camera rendered through Scene.render and through the CPU oracle."""
+    from oracle import oracle
+    from raytracer_amd import glm_camera as g
+    pos, faces = _soup()
+    w, h, n = 160, 96, 6
+    d = _run_demo(tmp_path, pos, faces, render=("walk", w, h, n))
+    cam = g.Camera(); cam.SetView((2, 2, 2), (0, 0, 0), (0, 1, 0)); cam.SetAspect(np.float32(w) / np.float32(h))
+    man = g.CameraManipulator(); man.SetCamera(cam)
+    p1, p2, pw, ph = g.default_portals()
+    man.KeyboardDown(g.KEY_W)
+    us, restarts = [], []
+    for k in range(n):
+        if k + 2 == n:
+            man.KeyboardUp(g.KEY_W)
+        restarts.append(man.Update(np.float32(1.0) / np.float32(60.0), p1, p2, pw, ph))
+        us.append(g.frame_uniforms(cam, p1, p2, pw, ph, time=np.float32(k) / np.float32(60.0)))
+    assert np.array_equal(np.stack(us).view(np.uint32), d["uniforms"].view(np.uint32))
+    assert restarts[:n - 2] == [True] * (n - 2)
+    eyes = np.stack(us)[:, 16:19]
+    assert np.allclose(np.linalg.norm(eyes[1] - eyes[0]), 16.0 / 60.0, atol=1e-4) and not np.array_equal(eyes[n - 3], eyes[0])
+    first = max(k for k in range(n) if restarts[k])          # accumulation restarts there
+    o = _python_octree(pos, faces)
+    sc = api.Scene.from_octree(o)
+    osc = oracle.OracleScene(o.as_dict(), None)
+    acc, depth, oacc = None, None, np.zeros((h, w, 4), np.float32)
+    for i, k in enumerate(range(first, n)):
+        r = sc.render(us[k], w, h, accum_index=i + 1, color=acc, planes=False)
+        acc, depth = r["rgba"], r["depth"]
+        oacc = osc.render(us[k], w, h, accum_index=i + 1, rgba=oacc, taps=False)["rgba"]
+    sc.close()
+    assert np.array_equal(d["rgba"].view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(d["depth"].view(np.uint32), depth.view(np.uint32))
+    assert np.array_equal(d["rgba"].view(np.uint32), oacc.view(np.uint32))
