@@ -110,6 +110,28 @@ class OracleScene:
         return o
 
 
+def depth_attachment(depth) -> np.ndarray:
+    """Value the reference's GL_DEPTH_COMPONENT24 attachment (/root/reference/app/core/src/Framebuffer.cpp:10-12) stores
+    for a gl_FragDepth plane: clamp to [0, 1], times 2^24 - 1 exactly, round to nearest.  Pinned by the attachment
+    read-backs of the llvmpipe fixtures (tests/test_oracle_golden.py)."""
+    d = np.asarray(depth, dtype=np.float32).astype(np.float64)
+    d = np.where(np.isnan(d), 0.0, np.clip(d, 0.0, 1.0))
+    return np.rint(d * 16777215.0).astype(np.uint32)
+
+
+def overlay_composite(color, depth24, frag_color, frag_depth24, frag_mask=None):
+    """Per-fragment operations of the reference's overlay draws (/root/reference/app/core/src/App.cpp:54,142-145):
+    depth test GL_LEQUAL against the attachment, depth writes on, blending off.  Returns new (color, depth24)."""
+    color, depth24 = np.array(color, dtype=np.float32), np.array(depth24, dtype=np.uint32)
+    fz = np.asarray(frag_depth24, dtype=np.uint32)
+    ok = fz <= depth24
+    if frag_mask is not None:
+        ok &= np.asarray(frag_mask) != 0
+    color[ok] = np.asarray(frag_color, dtype=np.float32)[ok]
+    depth24[ok] = fz[ok]
+    return color, depth24
+
+
 def math(op: str, x, y=None):
     ops = {"sin": 0, "cos": 1, "log2": 2, "exp2": 3, "pow": 4}
     x = np.ascontiguousarray(x, np.float32)

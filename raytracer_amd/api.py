@@ -34,6 +34,8 @@ EXPORTED_SYMBOLS = [
     "rt_vec3_normalize", "rt_camera_init", "rt_camera_set_view", "rt_camera_set_proj", "rt_camera_view_proj", "rt_camera_inv_view_proj", "rt_portal_difference_matrix", "rt_portal_ray",
     "rt_manipulator_init", "rt_manipulator_set_camera", "rt_manipulator_update", "rt_manipulator_key", "rt_manipulator_mouse_move", "rt_manipulator_mouse_wheel",
     "rt_uniforms_set_camera", "rt_uniforms_set_portals",
+    # include/rt_overlay.h
+    "rt_depth_to_attachment", "rt_overlay_composite",
 ]
 
 
@@ -131,6 +133,69 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = lib().rt_device_count(C.byref(n))
     return n.value if rc == RT_OK else 0
+
+
+def _is_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _plane_ptr(x, dtype, n, name):
+    """Pointer, memory space and a keep-alive reference of a plane given as a numpy array or a contiguous GPU tensor."""
+    if _is_tensor(x):
+        if not x.is_cuda or not x.is_contiguous() or x.numel() != n:
+            raise ValueError(f"{name}: a contiguous GPU tensor of {n} elements is required")
+        return x.data_ptr(), RT_MEM_DEVICE, x
+    a = np.ascontiguousarray(x, dtype=dtype)
+    if a.size != n:
+        raise ValueError(f"{name}: {n} elements are required")
+    return a.ctypes.data, RT_MEM_HOST, a
+
+
+def depth_to_attachment(depth, out=None, stream: int | None = None):
+    """rt_depth_to_attachment: the 24-bit values the reference's depth attachment holds for a gl_FragDepth plane
+    (Framebuffer.cpp:10-12).  numpy in -> numpy uint32 out (staged); GPU tensor in -> GPU int32 tensor out (same bits)."""
+    L = lib()
+    L.rt_depth_to_attachment.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    if _is_tensor(depth):
+        import torch
+        if depth.dtype != torch.float32:
+            raise ValueError("depth: a float32 tensor is required")
+        if out is None:
+            out = torch.empty(depth.shape, dtype=torch.int32, device=depth.device)
+        n = depth.numel()
+        p_in, mem, _k1 = _plane_ptr(depth, None, n, "depth")
+        p_out, _, _k2 = _plane_ptr(out, None, n, "out")
+        _check(L.rt_depth_to_attachment(p_in, p_out, n, mem, stream if stream is not None else torch.cuda.current_stream().cuda_stream))
+        return out
+    d = np.ascontiguousarray(depth, dtype=np.float32)
+    z = np.empty(d.shape, dtype=np.uint32) if out is None else out
+    _check(L.rt_depth_to_attachment(d.ctypes.data, z.ctypes.data, d.size, RT_MEM_HOST, None))
+    return z
+
+
+def overlay_composite(color, depth24, frag_color, frag_depth24, frag_mask=None, stream: int | None = None):
+    """rt_overlay_composite: GL_LEQUAL depth-tested write of one layer of rasterised fragments into `color` ([..., 4]
+    float32) and `depth24`, in place (App.cpp:54,142-145).  All planes numpy arrays, or all contiguous GPU tensors
+    (depth planes int32 holding the 24-bit values, mask uint8)."""
+    L = lib()
+    L.rt_overlay_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    tensors = _is_tensor(color)
+    n = depth24.numel() if tensors else int(np.asarray(depth24).size)
+    if tensors:
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+    elif not (isinstance(color, np.ndarray) and color.dtype == np.float32 and color.flags.c_contiguous and isinstance(depth24, np.ndarray) and depth24.dtype == np.uint32 and depth24.flags.c_contiguous):
+        raise ValueError("color must be a C-contiguous float32 array and depth24 a C-contiguous uint32 array (they are updated in place)")
+    pc, mem, _k1 = _plane_ptr(color, np.float32, 4 * n, "color")
+    pz, _, _k2 = _plane_ptr(depth24, np.uint32, n, "depth24")
+    pfc, m3, _k3 = _plane_ptr(frag_color, np.float32, 4 * n, "frag_color")
+    pfz, m4, _k4 = _plane_ptr(frag_depth24, np.uint32, n, "frag_depth24")
+    pm, m5, _k5 = (None, mem, None) if frag_mask is None else _plane_ptr(frag_mask, np.uint8, n, "frag_mask")
+    if len({mem, m3, m4, m5}) != 1:
+        raise ValueError("all planes must live in the same memory space")
+    _check(L.rt_overlay_composite(pc, pz, pfc, pfz, pm, n, mem, stream))
+    return color, depth24
 
 
 IDENTITY = np.eye(4, dtype=np.float32)

@@ -149,3 +149,28 @@ def test_oracle_eight_frame_accumulation(scene):
         u[20] = t
         acc = osc.render(u, w, h, accum_index=k + 1, rgba=acc, taps=False)["rgba"]
     assert np.array_equal(bits(acc), bits(z["rgba"]))
+
+
+ATTACHMENT_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref*.npz")) if "attachment_depth" in np.load(f).files)
+
+
+def attachment_values(z):
+    """24-bit values behind the GL_FLOAT read-back of the reference's depth attachment (value / (2^24 - 1) as a float)."""
+    a = z["attachment_depth"]
+    v = np.rint(a.astype(np.float64) * 16777215.0).astype(np.uint32)
+    assert np.array_equal(bits((v.astype(np.float64) / 16777215.0).astype(np.float32)), bits(a))   # the read-back is exactly such a value
+    return v
+
+
+@pytest.mark.parametrize("path", ATTACHMENT_FILES, ids=[os.path.basename(p)[:-4] for p in ATTACHMENT_FILES])
+def test_depth_attachment_values_match_llvmpipe(path):
+    """What the 24-bit depth attachment holds after the reference's draw, against the float the shader wrote."""
+    z = np.load(path)
+    assert np.array_equal(oracle.depth_attachment(z["depth"]), attachment_values(z))
+
+
+def test_depth_attachment_fixture_coverage():
+    assert len(ATTACHMENT_FILES) >= 20
+    seen = np.unique(np.concatenate([attachment_values(np.load(p)).ravel() for p in ATTACHMENT_FILES]))
+    assert len(seen) > 100000 and seen.max() == 16777215 and seen.min() < 16777215 * 0.8      # (the fixtures cover depths from 0.785 to 1)
+    assert np.array_equal(oracle.depth_attachment(np.array([-1.0, 0.0, 0.5, 1.0, 2.0, np.nan], np.float32)), [0, 0, 8388608, 16777215, 16777215, 0])
