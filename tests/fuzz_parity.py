@@ -1,0 +1,78 @@
+"""Randomised parity run, by hand on a GPU box (not collected by pytest):  python tests/fuzz_parity.py [--views N] [--seed S] [--scene bunny|small]
+
+Renders random views of the bunny scene -- camera anywhere around and inside the scene, random time, recursion limit,
+blur, portal placement, clip planes, frame size -- with every pipeline of the HIP library and with the CPU oracle, and
+compares colour, depth and the primary-hit planes bit for bit.  Prints one line per mismatch and a summary; exit code 1 on
+any mismatch."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def random_view(rng):
+    from raytracer_amd.camera import Camera, Portals, normalize
+    from raytracer_amd.params import Uniforms
+    kind = rng.integers(0, 4)
+    if kind == 0:      # orbiting the scene
+        a, r = rng.uniform(0, 2 * np.pi), rng.uniform(1.5, 9.0)
+        eye = (r * np.cos(a), rng.uniform(0.2, 5.0), r * np.sin(a)); at = (rng.uniform(-1, 1), rng.uniform(0, 1.5), rng.uniform(-1, 1))
+    elif kind == 1:    # among the small spheres
+        eye = (rng.uniform(-10, 10), rng.uniform(0.1, 1.2), rng.uniform(-10, 10)); at = (rng.uniform(-10, 10), rng.uniform(0, 2), rng.uniform(-10, 10))
+    elif kind == 2:    # near the portals
+        eye = (rng.uniform(4, 9), rng.uniform(0.5, 4), rng.uniform(-1, 7)); at = (7.0 + rng.uniform(-1, 1), 2.0, rng.choice([1.0, 5.0]) + rng.uniform(-1, 1))
+    else:              # inside / just outside the mesh's box
+        eye = (rng.uniform(-1.2, 1.2), rng.uniform(0.0, 2.0), rng.uniform(-1.2, 1.2)); at = (rng.uniform(-3, 3), rng.uniform(-1, 3), rng.uniform(-3, 3))
+    w, h = [(128, 128), (192, 64), (64, 160), (256, 128)][rng.integers(0, 4)]
+    cam = Camera(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), fovy=float(rng.uniform(0.5, 2.2)), aspect=w / h,
+                 z_near=float(10 ** rng.uniform(-3, -0.5)), z_far=float(10 ** rng.uniform(1, 3.5)))
+    portals = Portals()
+    if rng.uniform() < 0.4:
+        d1 = normalize(rng.normal(size=3) * (1, 0.2, 1)); d2 = normalize(rng.normal(size=3) * (1, 0.2, 1))
+        portals = Portals(position_1=tuple(rng.uniform(-6, 8, 3) * (1, 0.3, 1) + (0, 1.5, 0)), direction_1=tuple(np.float32(d1).tolist()),
+                          position_2=tuple(rng.uniform(-6, 8, 3) * (1, 0.3, 1) + (0, 1.5, 0)), direction_2=tuple(np.float32(d2).tolist()),
+                          width=float(rng.uniform(0.5, 4)), height=float(rng.uniform(0.5, 4)))
+    u = Uniforms.from_camera(cam, time=float(rng.choice([0.0, rng.uniform(0, 100), rng.uniform(0, 1e5)])), max_recursion_limit=int(rng.integers(0, 9)),
+                             blur_amount=float(rng.choice([1e-5, 0.0, rng.uniform(0, 0.2)])), portals=portals)
+    return u.pack(), w, h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--scene", default="bunny", choices=["bunny", "small"], help="small: a cluster of meshes carrying all seven materials on triangles")
+    a = ap.parse_args()
+    from oracle import oracle
+    from raytracer_amd import api, scenes
+    rng = np.random.default_rng(a.seed)
+    oc = scenes.default_octree() if a.scene == "bunny" else scenes.small_test_scene()
+    sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
+    osc = oracle.OracleScene(oc.as_dict(), sky)
+    sc = api.Scene.from_octree(oc); sc.set_skybox(sky)
+    bad = 0
+    for v in range(a.views):
+        u, w, h = random_view(rng)
+        want = osc.render(u, w, h)
+        for pipe in ("megakernel", "wavefront", "persistent"):
+            sc.set_pipeline(pipe)
+            got = sc.render(u, w, h)
+            traced = want["nrays"] > 0
+            diffs = {k: int((np.ascontiguousarray(got[k]).view(np.uint32) != np.ascontiguousarray(want[k]).view(np.uint32)).sum()) for k in ("rgba", "depth")}
+            diffs.update({k: int((got[k] != want[k]).sum()) for k in ("kind", "slot", "nrays")})
+            diffs["t"] = int((got["t"].view(np.uint32)[traced] != want["t"].view(np.uint32)[traced]).sum())
+            if any(diffs.values()):
+                bad += 1
+                print(f"MISMATCH view {v} seed {a.seed} {pipe} {w}x{h} limit {int(u[19:20].view(np.uint32)[0])}: {diffs}", flush=True)
+        if v % 20 == 19:
+            print(f"{v + 1} views, {bad} mismatching renders", flush=True)
+    sc.close()
+    print(f"done: {a.views} views x 3 pipelines, {bad} mismatching renders")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
