@@ -1,0 +1,53 @@
+"""Test infrastructure, run by hand where /root/reference exists:  python -m oracle.fuzz_vs_reference [--views N] [--seed S]
+
+Random views (the generator of tests/fuzz_parity.py, frame sizes forced to powers of two so that the closed-form NDC
+equals the rasteriser's) rendered by the reference's own shader on llvmpipe (oracle/refrun.py) and by the CPU restatement
+(oracle/rt_oracle.c); colour, the shader's depth, hit kind, slot, distance and segment count are compared bit for bit."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=101)
+    a = ap.parse_args()
+    from fuzz_parity import random_view
+    from oracle import oracle, refrun
+    from oracle.gen_fixtures import bunny_scene
+    refrun.build()
+    assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+    rng = np.random.default_rng(a.seed)
+    scene = bunny_scene()
+    sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
+    osc = oracle.OracleScene(scene, sky)
+    bad = 0
+    for v in range(a.views):
+        u, _, _ = random_view(rng)
+        w, h = [(128, 128), (128, 64), (64, 128)][int(rng.integers(0, 3))]
+        # the aspect ratio baked into the matrix no longer matches the frame: any matrix is a valid input
+        col = refrun.run_reference(scene, u, w, h, sky=sky)
+        hit = refrun.run_reference(scene, u, w, h, sky=sky, tap="hit")
+        o = osc.render(u, w, h)
+        traced = hit["nrays"] > 0
+        diffs = {"rgb": int((o["rgba"][..., :3].view(np.uint32) != col["rgba"][..., :3].view(np.uint32)).sum()),
+                 "kind": int((o["kind"] != hit["kind"]).sum()), "slot": int((o["slot"] != hit["slot"]).sum()), "nrays": int((o["nrays"] != hit["nrays"]).sum()),
+                 "t": int((o["t"].view(np.uint32)[traced] != hit["t"].view(np.uint32)[traced]).sum()),
+                 "depth24": int((oracle.depth_attachment(o["depth"]) != np.rint(col["depth"].astype(np.float64) * 16777215.0).astype(np.uint32)).sum())}
+        if any(diffs.values()):
+            bad += 1
+            print(f"MISMATCH view {v} seed {a.seed} {w}x{h} limit {int(u[19:20].view(np.uint32)[0])}: {diffs}", flush=True)
+        print(f"view {v + 1}/{a.views}: limit {int(u[19:20].view(np.uint32)[0])}, {bad} mismatching so far", flush=True)
+    print(f"done: {a.views} views, {bad} mismatching")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
