@@ -56,6 +56,11 @@ VIEWS = {
     "blur": dict(cam=Camera(aspect=1.0), size=(128, 128), kw=dict(blur_amount=0.2)),
     # other clip planes: gl_FragDepth is a function of z_near / z_far (frag:352-354), hits beyond z_far clamp to 1
     "depthrange": dict(cam=Camera(aspect=1.0, z_near=0.5, z_far=6.0), size=(128, 128)),
+    # near planes far out: gl_FragDepth values over the whole of [0, 1] (with the default planes they stay above 0.78), which
+    # is where the 24-bit depth attachment's rounding of small values shows
+    "znear03": dict(cam=Camera(aspect=1.0, z_near=0.3, z_far=1000.0), size=(128, 128)),
+    "znear1": dict(cam=Camera(eye=(3.0, 1.5, 0.5), at=(-0.3, 1.9, 0.0), aspect=1.0, z_near=1.0, z_far=40.0), size=(128, 128)),
+    "znear2": dict(cam=Camera(eye=(-2.0, 2.5, 3.0), at=(0.0, 1.0, 0.0), aspect=1.0, z_near=2.5, z_far=300.0), size=(128, 128)),
     # portals away from their default places, neither axis-aligned: both difference matrices are general rotations
     "portal_custom": dict(cam=Camera(eye=(2.0, 2.0, 3.5), at=(0.0, 1.5, 0.0), aspect=1.0), size=(128, 128),
                           kw=dict(portals=Portals(position_1=(0.9, 1.9, 2.2), direction_1=tuple(normalize((0.3, 0.0, 1.0)).astype(np.float32).tolist()),

@@ -112,11 +112,12 @@ class OracleScene:
 
 def depth_attachment(depth) -> np.ndarray:
     """Value the reference's GL_DEPTH_COMPONENT24 attachment (/root/reference/app/core/src/Framebuffer.cpp:10-12) stores
-    for a gl_FragDepth plane: clamp to [0, 1], times 2^24 - 1 exactly, round to nearest.  Pinned by the attachment
-    read-backs of the llvmpipe fixtures (tests/test_oracle_golden.py)."""
-    d = np.asarray(depth, dtype=np.float32).astype(np.float64)
-    d = np.where(np.isnan(d), 0.0, np.clip(d, 0.0, 1.0))
-    return np.rint(d * 16777215.0).astype(np.uint32)
+    for a gl_FragDepth plane, as llvmpipe converts it: clamp to [0, 1], multiply by 2^24 - 1 IN FLOAT (one rounding: below
+    0.5 the product is rounded to a multiple of 1/2 or finer), then round to the nearest integer, ties to even.  Pinned by
+    the attachment read-backs of the llvmpipe fixtures (tests/test_oracle_golden.py)."""
+    d = np.asarray(depth, dtype=np.float32)
+    d = np.where(np.isnan(d), np.float32(0.0), np.clip(d, np.float32(0.0), np.float32(1.0))).astype(np.float32)
+    return np.rint(d * np.float32(16777215.0)).astype(np.uint32)
 
 
 def overlay_composite(color, depth24, frag_color, frag_depth24, frag_mask=None):

@@ -18,7 +18,7 @@ constexpr unsigned BLOCK = 256;
 // Framebuffer.cpp:10-12: float depth -> 24-bit unsigned normalised, as the depth attachment stores it.
 __device__ __forceinline__ uint32_t to_depth24(float d) {
     const float c = fminf(fmaxf(d, 0.0f), 1.0f);                 // GL clamps the fragment depth; NaN becomes 0
-    return (uint32_t)__builtin_rint((double)c * 16777215.0);     // exact product, ties to even
+    return (uint32_t)__builtin_rintf(c * 16777215.0f);           // the product rounded to float first, then ties to even
 }
 
 __global__ __launch_bounds__(BLOCK) void depth_to_attachment_kernel(const float *__restrict__ depth, uint32_t *__restrict__ out, size_t n) {

@@ -172,5 +172,5 @@ def test_depth_attachment_values_match_llvmpipe(path):
 def test_depth_attachment_fixture_coverage():
     assert len(ATTACHMENT_FILES) >= 20
     seen = np.unique(np.concatenate([attachment_values(np.load(p)).ravel() for p in ATTACHMENT_FILES]))
-    assert len(seen) > 100000 and seen.max() == 16777215 and seen.min() < 16777215 * 0.8      # (the fixtures cover depths from 0.785 to 1)
+    assert len(seen) > 100000 and seen.max() == 16777215 and seen.min() == 0 and (seen < 8388608).sum() > 2000      # depths below 0.5, where the float product rounds to halves
     assert np.array_equal(oracle.depth_attachment(np.array([-1.0, 0.0, 0.5, 1.0, 2.0, np.nan], np.float32)), [0, 0, 8388608, 16777215, 16777215, 0])
