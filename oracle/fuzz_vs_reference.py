@@ -1,4 +1,4 @@
-"""Test infrastructure, run by hand where /root/reference exists:  python -m oracle.fuzz_vs_reference [--views N] [--seed S]
+"""Test infrastructure, run by hand where /root/reference exists:  python -m oracle.fuzz_vs_reference [--views N] [--seed S] [--scene bunny|small]
 
 Random views (the generator of tests/fuzz_parity.py, frame sizes forced to powers of two so that the closed-form NDC
 equals the rasteriser's) rendered by the reference's own shader on llvmpipe (oracle/refrun.py) and by the CPU restatement
@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=40)
     ap.add_argument("--seed", type=int, default=101)
+    ap.add_argument("--scene", default="bunny", choices=["bunny", "small"], help="small: a cluster of meshes carrying all seven materials on triangles")
     a = ap.parse_args()
     from fuzz_parity import random_view
     from oracle import oracle, refrun
@@ -25,7 +26,11 @@ def main():
     refrun.build()
     assert refrun.available(), "needs /root/reference and the llvmpipe runner"
     rng = np.random.default_rng(a.seed)
-    scene = bunny_scene()
+    if a.scene == "bunny":
+        scene = bunny_scene()
+    else:
+        from raytracer_amd import scenes          # (host-side octree builder of the product; its arrays equal the octree oracle's)
+        scene = scenes.small_test_scene().as_dict()
     sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
     osc = oracle.OracleScene(scene, sky)
     bad = 0
