@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=40)
     ap.add_argument("--seed", type=int, default=101)
+    ap.add_argument("--any-size", action="store_true", help="frame sizes 1..200 in both directions; the rasteriser's interpolated NDC of each size is captured from llvmpipe and handed to the restatement as a table")
     ap.add_argument("--scene", default="bunny", choices=["bunny", "small"], help="small: a cluster of meshes carrying all seven materials on triangles")
     a = ap.parse_args()
     from fuzz_parity import random_view
@@ -38,9 +39,14 @@ def main():
         u, _, _ = random_view(rng)
         w, h = [(128, 128), (128, 64), (64, 128)][int(rng.integers(0, 3))]
         # the aspect ratio baked into the matrix no longer matches the frame: any matrix is a valid input
+        ndc = None
+        if a.any_size:
+            from oracle.gen_fixtures import capture_ndc
+            w, h = int(rng.integers(1, 201)), int(rng.integers(1, 201))
+            ndc = capture_ndc(w, h)
         col = refrun.run_reference(scene, u, w, h, sky=sky)
         hit = refrun.run_reference(scene, u, w, h, sky=sky, tap="hit")
-        o = osc.render(u, w, h)
+        o = osc.render(u, w, h, ndc=ndc)
         traced = hit["nrays"] > 0
         diffs = {"rgb": int((o["rgba"][..., :3].view(np.uint32) != col["rgba"][..., :3].view(np.uint32)).sum()),
                  "kind": int((o["kind"] != hit["kind"]).sum()), "slot": int((o["slot"] != hit["slot"]).sum()), "nrays": int((o["nrays"] != hit["nrays"]).sum()),

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--views", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--near-first", action="store_true", help="also render with RT_ORDER_NEAR_FIRST and count the pixels whose colour differs from the oracle's (that mode is held to a tolerance, not to bit identity: differences are reported, not failures)")
+    ap.add_argument("--ndc-table", action="store_true", help="hand both sides a per-pixel NDC table (the closed form moved by a few units in the last place, as a rasteriser's interpolation does) instead of the closed form")
     ap.add_argument("--scene", default="bunny", choices=["bunny", "small"], help="small: a cluster of meshes carrying all seven materials on triangles")
     a = ap.parse_args()
     from oracle import oracle
@@ -58,10 +59,18 @@ def main():
     nf_pixels = nf_diff = nf_beyond = nf_slot = 0
     for v in range(a.views):
         u, w, h = random_view(rng)
-        want = osc.render(u, w, h)
+        ndc = None
+        if a.ndc_table:
+            x = (np.float32(2.0) * (np.arange(w, dtype=np.float32) + np.float32(0.5)) / np.float32(w) - np.float32(1.0)).astype(np.float32)
+            y = (np.float32(2.0) * (np.arange(h, dtype=np.float32) + np.float32(0.5)) / np.float32(h) - np.float32(1.0)).astype(np.float32)
+            nx = np.broadcast_to(x, (h, w)).copy(); ny = np.broadcast_to(y[:, None], (h, w)).copy()
+            nx = (nx.view(np.int32) + rng.integers(-3, 4, (h, w), dtype=np.int32)).view(np.float32)
+            ny = (ny.view(np.int32) + rng.integers(-3, 4, (h, w), dtype=np.int32)).view(np.float32)
+            ndc = (nx, ny)
+        want = osc.render(u, w, h, ndc=ndc)
         for pipe in ("megakernel", "wavefront", "persistent"):
             sc.set_pipeline(pipe)
-            got = sc.render(u, w, h)
+            got = sc.render(u, w, h, ndc=ndc)
             traced = want["nrays"] > 0
             diffs = {k: int((np.ascontiguousarray(got[k]).view(np.uint32) != np.ascontiguousarray(want[k]).view(np.uint32)).sum()) for k in ("rgba", "depth")}
             diffs.update({k: int((got[k] != want[k]).sum()) for k in ("kind", "slot", "nrays")})
