@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/rt_camera.h"
+#include "../../include/rt_overlay.h"
 #include "../../include/rt_hotpath.h"
 
 namespace rt {
@@ -239,6 +240,17 @@ inline rt_uniforms FrameUniforms(const Camera &camera, const Portal &portal_1, c
     rt_uniforms_set_portals(&u, &p1.x, &d1.x, &p2.x, &d2.x, portal_width, portal_height);
     u.time = time; u.max_recursion_limit = max_recursion_limit; u.blur_amount = blur_amount;
     return u;
+}
+
+// The depth-buffer side of the overlay pass on device planes (Framebuffer.cpp:10-12, App.cpp:54,142-145): the 24-bit
+// values the reference's depth attachment holds for the plane RayTracePass::Render wrote, and the GL_LEQUAL merge of one
+// layer of fragments from a rasteriser of the caller's choice.  Both are ordered on `stream`.
+inline void DepthToAttachment(const float *depth_dev, uint32_t *depth24_dev, size_t n_pixels, void *stream = nullptr) {
+    check(rt_depth_to_attachment(depth_dev, depth24_dev, n_pixels, RT_MEM_DEVICE, stream));
+}
+inline void OverlayComposite(float *color_dev, uint32_t *depth24_dev, const float *frag_color_dev, const uint32_t *frag_depth24_dev, const uint8_t *frag_mask_dev,
+                             size_t n_pixels, void *stream = nullptr) {
+    check(rt_overlay_composite(color_dev, depth24_dev, frag_color_dev, frag_depth24_dev, frag_mask_dev, n_pixels, RT_MEM_DEVICE, stream));
 }
 
 }  // namespace rt
