@@ -24,7 +24,7 @@ extern "C" {
  * before the conversion to integer, which matters below 0.5.  `depth` is the plane rt_target.depth receives.  Pinned by
  * read-backs of the attachment in the reference runs on llvmpipe (the GL_FLOAT read-back of the attachment equals
  * float(depth24 / (2^24 - 1)) in every pixel of every fixture, depths from 0 to 1).
- * memory: RT_MEM_DEVICE (pointers on the current HIP device; the call is ordered on `stream`, a hipStream_t or NULL, and
+ * memory: RT_MEM_DEVICE (all planes on one HIP device, found from the pointers; the call is ordered on `stream`, a hipStream_t or NULL, and
  * returns after the enqueue) or RT_MEM_HOST (staged through device memory; returns when done). */
 int rt_depth_to_attachment(const float *depth, uint32_t *depth24, size_t n_pixels, int memory, void *stream);
 

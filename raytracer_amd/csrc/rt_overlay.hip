@@ -67,6 +67,20 @@ struct Staged {
     }
 };
 
+// Makes the device that owns `p` current for the lifetime of the object (planes may live on another GPU than the
+// calling thread's current one); restores the previous device afterwards.
+struct OnDeviceOf {
+    int prev = -1, dev = -1;
+    explicit OnDeviceOf(const void *p) {
+        hipPointerAttribute_t at;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice) dev = at.device;
+        else (void)hipGetLastError();
+        if (dev >= 0 && dev != prev) (void)hipSetDevice(dev);
+    }
+    ~OnDeviceOf() { if (prev >= 0 && dev >= 0 && dev != prev) (void)hipSetDevice(prev); }
+};
+
 int device_ready() {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return rt_internal_set_error(RT_ENODEVICE, "no HIP device (there is no CPU fallback)");
@@ -82,6 +96,7 @@ extern "C" int rt_depth_to_attachment(const float *depth, uint32_t *depth24, siz
     if (n == 0) return RT_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (memory == RT_MEM_DEVICE) {
+        OnDeviceOf guard(depth24);
         depth_to_attachment_kernel<<<grid_for((n + 3) / 4), BLOCK, 0, st>>>(depth, depth24, n);
         HIP_OK(hipGetLastError());
         return RT_OK;
@@ -105,6 +120,7 @@ extern "C" int rt_overlay_composite(float *color, uint32_t *depth24, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (memory == RT_MEM_DEVICE) {
         if (((uintptr_t)color | (uintptr_t)frag_color) & 15u) return rt_internal_set_error(RT_EINVAL, "rt_overlay_composite: colour planes must be 16-byte aligned");
+        OnDeviceOf guard(depth24);
         overlay_composite_kernel<<<grid_for(n), BLOCK, 0, st>>>(reinterpret_cast<float4 *>(color), depth24, reinterpret_cast<const float4 *>(frag_color), frag_depth24, frag_mask, n);
         HIP_OK(hipGetLastError());
         return RT_OK;
