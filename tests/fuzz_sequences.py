@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="frames of 2000..3840 x 1200..2160 pixels (the sizes at which sequences are traced four frames per launch and blended in the kernel)")
     a = ap.parse_args()
     from oracle import oracle
     from raytracer_amd import api, dist as rdist, scenes
@@ -34,7 +35,9 @@ def main():
         w, h = int(rng.integers(1, 401)), int(rng.integers(1, 301))
         if rng.uniform() < 0.15:
             w, h = int(rng.integers(600, 1400)), int(rng.integers(400, 800))     # large enough for several sub-frames
-        n = int(rng.integers(1, 15))
+        if a.big:
+            w, h = int(rng.integers(2000, 3841)), int(rng.integers(1200, 2161))
+        n = int(rng.integers(1, 10 if a.big else 15))
         band_rows = int(rng.choice([1, 2, 7, 16, 16, 16, 32]))
         parts = int(rng.choice([1, 1, 2, 3, 5]))
         part = int(rng.integers(0, parts))
