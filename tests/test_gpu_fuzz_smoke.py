@@ -1,0 +1,25 @@
+"""Short runs of the randomised parity tools (tests/fuzz_*.py) so that every GPU test run exercises them with a fixed
+seed; the long runs are made by hand."""
+import importlib
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("module,argv", [
+    ("fuzz_parity", ["--views", "40", "--seed", "3", "--near-first"]),
+    ("fuzz_parity", ["--views", "30", "--seed", "4", "--scene", "small", "--ndc-table"]),
+    ("fuzz_sequences", ["--cases", "25", "--seed", "3"]),
+    ("fuzz_octree", ["--cases", "25", "--seed", "3"]),
+    ("fuzz_scene_validation", ["--cases", "300", "--seed", "3"]),
+])
+def test_fuzz_tool_short_run(module, argv, monkeypatch, capsys):
+    monkeypatch.setattr(sys, "argv", [module] + argv)
+    rc = importlib.import_module(module).main()
+    out = capsys.readouterr().out
+    assert rc == 0, out
+    assert "MISMATCH" not in out and "done:" in out
+    if "--near-first" in argv:
+        assert "colour differs in 0," in out
