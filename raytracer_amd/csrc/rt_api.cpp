@@ -1,7 +1,7 @@
 // Host side of the C ABI declared in include/rt_hotpath.h: scene validation and re-flattening, device memory,
 // the render entry point.  Replaces the GL resource handling around the reference's render pass
 // (app/core/src/App.cpp:23-26,96-140, Buffer.cpp:3-14, Skybox.cpp:46-57, Framebuffer.cpp:6-12).
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <chrono>
@@ -11,23 +11,20 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <string>
 #include <vector>
 
 #include "rt_internal.h"
 
 namespace {
 
-thread_local std::string g_err;
+thread_local char g_err[512] = "";   // (a fixed buffer: reporting an error allocates nothing)
 thread_local int g_device = -1;   // -1: not chosen, use the current HIP device
 
 int fail(int code, const char *fmt, ...) {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
-    g_err = buf;
     return code;
 }
 #define HIP_TRY(expr)                                                                                     \
@@ -46,7 +43,13 @@ struct rt_scene {
     bool counting = false;
     // staging for host-memory targets
     void *s_color = nullptr, *s_depth = nullptr, *s_kind = nullptr, *s_slot = nullptr, *s_t = nullptr, *s_nrays = nullptr, *s_ndcx = nullptr, *s_ndcy = nullptr;
-    size_t s_pixels = 0;
+    size_t s_ndc_cap = 0, s_target_cap = 0;   // pixels the ndc tables / the colour and debug planes have room for (grow-only)
+    // Scene-owned scratch (cost maps, batch staging, wavefront workspace, tile counters) is shared by every render of the
+    // scene: a call on another stream than the previous one first waits for that one's work.
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    int n_cu = 256;
     // wavefront pipeline: a frame is cut into up to RT_MAX_SUBFRAMES interleaved sub-frames that run as independent
     // kernel chains on their own streams, so that the sparse tail of one chain overlaps the dense kernels of another
     int pipeline = RT_PIPELINE_AUTO;
@@ -99,7 +102,7 @@ struct DeviceGuard {
 void free_staging(rt_scene *s) {
     void **p[] = {&s->s_color, &s->s_depth, &s->s_kind, &s->s_slot, &s->s_t, &s->s_nrays, &s->s_ndcx, &s->s_ndcy};
     for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
-    s->s_pixels = 0;
+    s->s_ndc_cap = s->s_target_cap = 0;
 }
 
 // Frame-space pixel rectangle (x0, y0, x1, y1 inclusive) that the scene's octree bounds project to under the frame's
@@ -186,7 +189,7 @@ int upload(void **dst, const void *src, size_t bytes) {
 
 extern "C" {
 
-const char *rt_last_error(void) { return g_err.c_str(); }
+const char *rt_last_error(void) { return g_err; }
 int rt_internal_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
 
 // Verification hook (not part of the ABI): the kernels' short 1/x and sqrt sequences against the compiler's correctly rounded
@@ -298,6 +301,11 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     s->d.sky_w = s->d.sky_h = 0;
     for (int k = 0; k < 3; k++) { s->d.bounds_min[k] = bounds_min[k]; s->d.bounds_max[k] = bounds_max[k]; }
     s->d.max_depth = nb.max_depth;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) s->n_cu = v;
+        if (hipEventCreateWithFlags(&s->last_use, hipEventDisableTiming) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ENODEVICE, "cannot create an event"); }
+    }
     *out = s;
     if (trace) fprintf(stderr, "rt_scene_create ms: reference check %.1f | upload %.1f | node records %.1f (%u) | triangle records %.1f\n", t_check, t_upload, t_flatten, nb.n_nodes, ms_since(t_phase));
     return RT_OK;
@@ -501,6 +509,13 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
     hipStream_t st = (hipStream_t)f->stream;
+    // the scene's scratch buffers are written by every render: work issued on another stream is ordered behind the last call's
+    if (s->used && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_use, 0));
+    auto mark_use = [&]() -> int {
+        if (hipEventRecord(s->last_use, st) != hipSuccess) return fail(RT_ENODEVICE, "hipEventRecord failed");
+        s->last_stream = st; s->used = true;
+        return RT_OK;
+    };
 
     if (f->compact_rows > 1) return fail(RT_EINVAL, "compact_rows must be 0 or 1");
     RtLaunch L{};
@@ -510,6 +525,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     L.n_local_rows = band_rows_of(f);   // rows owned by this part: whole strips, the last one clipped by the kernel
     L.compact_rows = f->compact_rows;
     L.near_first = s->order == RT_ORDER_NEAR_FIRST ? 1u : 0u;
+    L.n_cu = (uint32_t)s->n_cu;
     L.counters = s->counting ? s->d_counters : nullptr;
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
 
@@ -520,8 +536,11 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^ (uint64_t)(n_frames > 1 ? 2 : 0) ^ (uint64_t)(s->order ? 4 : 0);
         pipeline = tuner_choose(s, key + 1, &measure);
     }
-    const bool wavefront = pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
-    const bool persistent = pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
+    bool wavefront = pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
+    bool persistent = pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
+    // a measurement belongs to the pipeline that actually runs every frame of the call: frames without any segment go
+    // through the one-kernel pipeline whatever was chosen
+    if (measure && (pipeline != RT_PIPELINE_MEGAKERNEL) && (min_limit < 1 || !(wavefront || persistent))) measure = false;
     // number of sub-frames: every one should still fill the machine (>= 64 strips of 16 rows x width)
     uint32_t K = 1;
     // (the one-kernel-per-frame pipeline orders its workgroups by measured cost instead, see attach_order: with that its
@@ -536,7 +555,15 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             const uint32_t rows = band_rows_of(&fj);
             if (wavefront) {
                 int wrc = ensure_workspace(&s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
-                if (wrc != RT_OK) return wrc;
+                if (wrc != RT_OK) {
+                    // (about 112 bytes per pixel.)  Under automatic selection a pipeline that cannot get its workspace is
+                    // given up for this workload instead of failing the render: the one-kernel pipeline needs none.
+                    if (s->pipeline != RT_PIPELINE_AUTO) return wrc;
+                    s->tuner.ms[RT_PIPELINE_WAVEFRONT] = 1e30; s->tuner.seen[RT_PIPELINE_WAVEFRONT] = 2;
+                    (void)hipGetLastError();   // (the failed allocation's error is handled here)
+                    wavefront = false; measure = false; pipeline = RT_PIPELINE_MEGAKERNEL; K = 1;
+                    break;
+                }
             } else if (persistent && !s->sub[j].pool) {
                 HIP_TRY(hipMalloc((void **)&s->sub[j].pool, rt_pool_bytes()));
             }
@@ -673,16 +700,21 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         L.ndc_x = f->ndc_x; L.ndc_y = f->ndc_y;
         L.color = t->color; L.depth = t->depth; L.hit_kind = t->hit_kind; L.hit_slot = t->hit_slot; L.hit_t = t->hit_t; L.n_rays = t->n_rays;
         if (launch_all(L, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
+        if (int mrc = mark_use()) return mrc;
         if (t->sync) HIP_TRY(hipStreamSynchronize(st));
         return RT_OK;
     }
     // Host target: stage through device buffers owned by the scene.
-    if (s->s_pixels != px + tpx) {
+    // (the two kinds of plane have capacities of their own: a compact band buffer and a full frame can hold the same
+    // number of pixels in total and still need planes of different sizes)
+    if (s->s_target_cap < tpx || s->s_ndc_cap < px || !s->s_color) {
+        const size_t ncap = std::max(px, s->s_ndc_cap), tcap = std::max<size_t>(std::max(tpx, s->s_target_cap), 1);
+        HIP_TRY(hipDeviceSynchronize());
         free_staging(s);
-        HIP_TRY(hipMalloc(&s->s_color, (tpx ? tpx : 1) * 16)); HIP_TRY(hipMalloc(&s->s_depth, (tpx ? tpx : 1) * 4)); HIP_TRY(hipMalloc(&s->s_kind, (tpx ? tpx : 1) * 4));
-        HIP_TRY(hipMalloc(&s->s_slot, (tpx ? tpx : 1) * 4)); HIP_TRY(hipMalloc(&s->s_t, (tpx ? tpx : 1) * 4)); HIP_TRY(hipMalloc(&s->s_nrays, (tpx ? tpx : 1) * 4));
-        HIP_TRY(hipMalloc(&s->s_ndcx, px * 4)); HIP_TRY(hipMalloc(&s->s_ndcy, px * 4));
-        s->s_pixels = px + tpx;
+        HIP_TRY(hipMalloc(&s->s_color, tcap * 16)); HIP_TRY(hipMalloc(&s->s_depth, tcap * 4)); HIP_TRY(hipMalloc(&s->s_kind, tcap * 4));
+        HIP_TRY(hipMalloc(&s->s_slot, tcap * 4)); HIP_TRY(hipMalloc(&s->s_t, tcap * 4)); HIP_TRY(hipMalloc(&s->s_nrays, tcap * 4));
+        HIP_TRY(hipMalloc(&s->s_ndcx, ncap * 4)); HIP_TRY(hipMalloc(&s->s_ndcy, ncap * 4));
+        s->s_ndc_cap = ncap; s->s_target_cap = tcap;
     }
     HIP_TRY(hipMemcpyAsync(s->s_color, t->color, tpx * 16, hipMemcpyHostToDevice, st));   // read-modify-write target (blend) and untouched bands
     if (f->ndc_x) {
@@ -699,6 +731,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     if (launch_all(L, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
     HIP_TRY(hipMemcpyAsync(t->color, s->s_color, tpx * 16, hipMemcpyDeviceToHost, st));
     for (Plane &p : planes) if (p.host) HIP_TRY(hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, st));
+    if (int mrc = mark_use()) return mrc;
     HIP_TRY(hipStreamSynchronize(st));
     return RT_OK;
 }
@@ -722,6 +755,7 @@ int rt_scene_destroy(rt_scene *s) {
         if (sb.probe.events) { for (uint32_t i = 0; i < 2 * sb.probe.capacity; i++) if (sb.probe.events[i]) (void)hipEventDestroy(sb.probe.events[i]); delete[] sb.probe.events; delete[] sb.probe.launches; }
     }
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+    if (s->last_use) (void)hipEventDestroy(s->last_use);
     if (s->stage) (void)hipFree(s->stage);
     if (s->tuner.a) (void)hipEventDestroy(s->tuner.a);
     if (s->tuner.b) (void)hipEventDestroy(s->tuner.b);

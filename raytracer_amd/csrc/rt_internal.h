@@ -56,6 +56,7 @@ struct RtLaunch {
     uint32_t width, height, accum_index, blend;
     uint32_t band_rows, band_parts, band_part, n_local_rows;
     uint32_t compact_rows;
+    uint32_t n_cu;                  // compute units of the device (sizes the persistent kernels' grids; 0: 256)
     uint32_t near_first;            // children of an octree node are visited nearest first instead of in the reference's order
     uint32_t sub_parts, sub_part;   // this launch renders sub-frame sub_part of sub_parts of the caller's band (1, 0: all of it)
     uint32_t hot[4];                // tile rectangle (x0, y0, x1, y1 inclusive, 16x16 tiles of the local rows) where the octree projects to; x1 < x0: none

@@ -995,9 +995,7 @@ DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
 #define RENDER_WAVES_PER_SIMD 6
 #endif
 #define RENDER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(LEVELS <= 19 ? 7 : LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3, LEVELS <= 19 ? 7 : LEVELS <= 20 ? RENDER_WAVES_PER_SIMD : 3)))
-#ifndef RENDER_BLOCK
 #define RENDER_BLOCK 256   // threads per workgroup = pixels per unit of the cost map (a 16x16 tile)
-#endif
 // BATCH: the launch traces B->n consecutive frames (see RtBatch), the expensive units of all frames still first.
 template <int LEVELS, bool COUNT, int BLOCK, bool BATCH>
 DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *B) {
@@ -1040,10 +1038,15 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
     const unsigned long long t_start = L.cost ? wall_clock64() : 0ull;
     const uint32_t q = BATCH ? blockIdx.x / groups : 0u;                       // BATCH: 8x8 tile index in the ordered list
     const uint32_t slot = BATCH ? q / UNIT_TILES : blockIdx.x;
-    const uint32_t unit = L.order ? L.order[slot] : slot;
+    // The order lists 16x16 tiles by their position in the frame (tile_y * tiles_x + tile_x), and so does the cost map: a
+    // tile keeps its cost when the rectangle the octree projects to -- which only decides the start order of a geometry's
+    // first launch -- moves with the camera.
+    const uint32_t tiles_x = (L.width + 15u) / 16u;
     uint32_t tile_x, tile_y;
-    path_tile(L, unit / (256u / RENDER_BLOCK), tile_x, tile_y);
-    PixelId p = pixel_of_tile(L, tile_x, tile_y, (unit % (256u / RENDER_BLOCK)) * RENDER_BLOCK + (BATCH ? (q % UNIT_TILES) * 64u + lane : threadIdx.x));
+    if (L.order) { const uint32_t id = L.order[slot]; tile_x = id % tiles_x; tile_y = id / tiles_x; }
+    else path_tile(L, slot, tile_x, tile_y);
+    const uint32_t unit = tile_y * tiles_x + tile_x;
+    PixelId p = pixel_of_tile(L, tile_x, tile_y, BATCH ? (q % UNIT_TILES) * 64u + lane : threadIdx.x);
     const bool in_frame = p.active;
     p.active = p.active && frame_ok;
     const bool fused_blend = BATCH && groups == 1u;
@@ -1102,7 +1105,7 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
         else if (!fused_blend) B->stage[(size_t)frame * B->stage_stride + (size_t)p.lr * L.width + p.x] = make_float4(out.x, out.y, out.z, 0.0f);
         if (L.n_rays && (!BATCH || frame + 1u == B->n)) L.n_rays[p.pi] = nrays;
     }
-    if (L.cost && (threadIdx.x & 63u) == 0) atomicMax(&L.cost[unit], (uint32_t)min(wall_clock64() - t_start, 0xFFFFFFFFull) + 1u);
+    if (L.cost && (threadIdx.x & 63u) == 0) atomicMax(&L.cost[unit], (uint32_t)min(wall_clock64() - t_start, 0xFFFFFFFEull) + 1u);
     if (fused_blend) {
         // the traversal stacks are dead once every wave is here: their LDS carries the samples to the first wave, which
         // applies them to its 64 pixels frame after frame (App.cpp:49,102-105)
@@ -1182,10 +1185,9 @@ __global__ __launch_bounds__(1024) void order_kernel(uint32_t *__restrict__ cost
 //                    result back and the wave refills its idle lanes together once enough of them wait
 //   shade_kernel     all segments, dense: cylinder, portals, hit assembly, scattering; finished paths are tonemapped
 //                    and blended into the target, continuing ones are compacted into the next depth's planes
-// Counters (uint32): ctr[QT_COUNT + (d&1)], ctr[QT_HEAD + (d&1)] traversal queue of depth d; ctr[ALIVE] paths that
-// continue past the depth being shaded (maintained only where the host asks for it).
+// Counters (uint32): ctr[QT_COUNT + (d&1)], ctr[QT_HEAD + (d&1)] traversal queue of depth d.
 // ================================================================================================
-enum { QT_COUNT = 0, QT_HEAD = 2, ALIVE = 4 };
+enum { QT_COUNT = 0, QT_HEAD = 2 };
 #define RANGE 1024u            // slots per workgroup-owned range (4 chunks of 256)
 #ifndef REFILL_IDLE
 #define REFILL_IDLE 16         // lanes that must be waiting before a traversal wave refills them together
@@ -1347,7 +1349,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
 }
 
 template <bool D0, bool COUNT>
-__global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles, uint32_t track_alive) {
+__global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles) {
     __shared__ uint32_t lds4[4];
     __shared__ PortalBasis lds_portals[2];
     stage_portals(lds_portals, L.u);
@@ -1420,10 +1422,7 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
         }
         out_count += total;
     }
-    if (threadIdx.x == 0) {
-        WS.live[nxt][blockIdx.x] = out_count;
-        if (track_alive && out_count) atomicAdd(&ctr[ALIVE], out_count);
-    }
+    if (threadIdx.x == 0) WS.live[nxt][blockIdx.x] = out_count;
     if (COUNT && L.counters) flush_counters(L.counters, cn);
 }
 
@@ -1603,7 +1602,6 @@ void launch_path(const RtDeviceScene &S, const RtLaunch &L, uint32_t *pool, uint
 
 template <int LEVELS>
 int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st, dim3 grid, const RtBatch *batch) {
-    grid.x *= 256u / RENDER_BLOCK;
     if (batch) {
         // one workgroup per 8x8 tile and group of RT_BATCH_BLOCK / 64 frames
         grid.x *= (RENDER_BLOCK / 64u) * rt_batch_groups(batch->n);
@@ -1656,7 +1654,7 @@ int rt_math_check(int op, unsigned long long out[2]) {
 }
 
 size_t rt_render_units(uint32_t width, uint32_t n_local_rows) {
-    return (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u) * (256u / RENDER_BLOCK);
+    return (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u);
 }
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows) {
     const size_t n_tiles = (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u);
@@ -1675,14 +1673,9 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
     const bool timed = probe && probe->used < probe->capacity;
     auto mark = [&](uint32_t which) { if (timed) (void)hipEventRecord(probe->events[2 * probe->used + which], st); };
     if (pool) {
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            n_cu = v;
-        }
+        const uint32_t n_cu = L.n_cu ? L.n_cu : 256u;
         const uint32_t n_units = n_tiles * 4u;
-        const uint32_t wgs = min((uint32_t)n_cu * PATH_WG_PER_CU, (n_units + 3u) / 4u);
+        const uint32_t wgs = min(n_cu * PATH_WG_PER_CU, (n_units + 3u) / 4u);
         (void)hipMemsetAsync(pool, 0, rt_pool_bytes(), st);
         mark(0);
         if (need <= 12) launch_path<12>(S, L, pool, n_tiles, st, dim3(wgs));
@@ -1700,19 +1693,18 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         else rc = launch_megakernel<RT_MAX_TREE_DEPTH + 2>(S, L, st, grid, batch);
         mark(1);
         if (batch && rt_batch_groups(batch->n) > 1u) hipLaunchKernelGGL(blend_batch_kernel, dim3((L.width * L.n_local_rows + 255u) / 256u), dim3(256), 0, st, L, *batch);
-        if (L.cost && L.order_next) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, L.cost, L.order_next, n_tiles * (256u / RENDER_BLOCK));
+        if (L.cost && L.order_next) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, L.cost, L.order_next, n_tiles);
         if (timed) probe->launches[probe->used++] = 1;
     } else {
         const bool count = L.counters != nullptr;
         const dim3 grid((uint32_t)rt_workspace_ranges(L.width, L.n_local_rows));   // one workgroup per slot range
-        const dim3 tgrid(256 * TRAVERSE_WG_PER_CU);                                  // persistent traversal workgroups
+        const dim3 tgrid((L.n_cu ? L.n_cu : 256u) * TRAVERSE_WG_PER_CU);             // persistent traversal workgroups
         (void)hipMemsetAsync(WS->ctr, 0, 8 * sizeof(uint32_t), st);
         hipLaunchKernelGGL(primary_sphere_kernel, dim3(1), dim3(128), 0, st, L, WS->prim);
+        // (every depth is enqueued: a depth no path reaches costs three launches that find empty ranges and an empty queue,
+        // whereas asking the device whether any path is left would block the caller inside an enqueue)
         const uint32_t limit = L.u.max_recursion_limit;
         for (uint32_t d = 0; d < limit; d++) {
-            // Paths rarely live long; past a few bounces ask the device now and then whether any is left.
-            const bool ask = d >= 7 && d + 1 < limit && (d & 3u) == 3u;
-            if (ask) (void)hipMemsetAsync(&WS->ctr[ALIVE], 0, sizeof(uint32_t), st);
             if (d == 0) hipLaunchKernelGGL((spheres_kernel<true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
             else hipLaunchKernelGGL((spheres_kernel<false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
             if (S.n_nodes) {
@@ -1723,18 +1715,12 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
                 else launch_traverse<RT_MAX_TREE_DEPTH + 2>(S, L, *WS, d, st, tgrid);
                 if (t) { mark(1); probe->launches[probe->used++] = 1; }
             }
-            const uint32_t track = ask ? 1u : 0u;
             if (d == 0) {
-                if (count) hipLaunchKernelGGL((shade_kernel<true, true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
-                else hipLaunchKernelGGL((shade_kernel<true, false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
+                if (count) hipLaunchKernelGGL((shade_kernel<true, true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
+                else hipLaunchKernelGGL((shade_kernel<true, false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
             } else {
-                if (count) hipLaunchKernelGGL((shade_kernel<false, true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
-                else hipLaunchKernelGGL((shade_kernel<false, false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles, track);
-            }
-            if (ask) {
-                uint32_t left = 0;
-                if (hipMemcpyAsync(&left, &WS->ctr[ALIVE], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) break;
-                if (left == 0) break;
+                if (count) hipLaunchKernelGGL((shade_kernel<false, true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
+                else hipLaunchKernelGGL((shade_kernel<false, false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
             }
         }
         rc = (int)hipGetLastError();

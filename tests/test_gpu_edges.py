@@ -198,3 +198,66 @@ def test_short_reciprocal_and_square_root_are_correctly_rounded_for_every_input(
     out = (C.c_ulonglong * 2)()
     assert api.lib().rt_internal_math_check(op, out) == api.RT_OK
     assert out[0] == 0, f"{name}: {out[0]} inputs differ, e.g. bits 0x{out[1]:08x}"
+
+
+def test_host_target_staging_survives_frames_with_equal_pixel_sums(small_pair):
+    """A compact band of a 100x150 frame (15 000 ndc entries, 5 000 target pixels) and a full 100x100 frame (10 000 of
+    each) have the same total: the staging planes of host-memory targets are sized per kind, so either order works."""
+    sc, osc = small_pair
+    cam = Camera(eye=(2.5, 2.5, 2.5), at=(0.0, 1.5, 0.0), aspect=1.0)
+    u = Uniforms.from_camera(cam).pack()
+
+    def band_frame(sc):
+        w, h = 100, 150
+        fr = api.make_frame(u, w, h, band=(50, 3, 1), compact=True)
+        rows = api.band_row_count(fr)
+        assert rows == 50
+        nx = np.tile((2.0 * (np.arange(w, dtype=np.float32) + 0.5) / np.float32(w) - 1.0).astype(np.float32), (h, 1))
+        ny = np.tile((2.0 * (np.arange(h, dtype=np.float32) + 0.5) / np.float32(h) - 1.0).astype(np.float32)[:, None], (1, w))
+        nx, ny = np.ascontiguousarray(nx), np.ascontiguousarray(ny)
+        fr.ndc_x, fr.ndc_y = nx.ctypes.data, ny.ctypes.data
+        col = np.zeros((rows, w, 4), np.float32)
+        tg = api.rt_target()
+        tg.memory, tg.sync, tg.color = api.RT_MEM_HOST, 1, col.ctypes.data
+        sc.render_raw(fr, tg)
+        o = osc.render(u, w, h, ndc=(nx, ny))
+        assert np.array_equal(bits(col), bits(o["rgba"][50:100])), "compact band"
+
+    def full_frame(sc):
+        same(osc.render(u, 100, 100), sc.render(u, 100, 100), "full frame")
+
+    for pipe in PIPELINES:
+        sc.set_pipeline(pipe)
+        band_frame(sc); full_frame(sc); band_frame(sc); full_frame(sc)
+    # and starting from the other kind of frame, on a scene whose staging planes do not exist yet
+    sc2 = api.Scene.from_octree(scenes.small_test_scene())
+    sc2.set_skybox(np.random.default_rng(1).integers(0, 256, size=(6, 64, 64, 4), dtype=np.uint8))
+    full_frame(sc2); band_frame(sc2); full_frame(sc2)
+    sc2.close()
+
+
+def test_renders_of_one_scene_on_two_streams_are_ordered(bunny_octree, test_sky):
+    """Scene-owned scratch (cost order, wavefront workspace, tile counters) is shared by all renders of a scene: calls
+    issued back to back with sync = 0 on two different streams must still give each target its own complete frame."""
+    import torch
+    from oracle import oracle
+    sc = api.Scene.from_octree(bunny_octree, device=0)
+    sc.set_skybox(test_sky)
+    w, h = 640, 360
+    us = [Uniforms.from_camera(Camera(aspect=w / h), time=k / 60.0, max_recursion_limit=3).pack() for k in range(6)]
+    osc = oracle.OracleScene(bunny_octree.as_dict(), test_sky)
+    want = [osc.render(u, w, h, taps=False)["rgba"] for u in us]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for pipe in PIPELINES:
+        sc.set_pipeline(pipe)
+        cols = [torch.zeros((h, w, 4), device="cuda") for _ in us]
+        torch.cuda.synchronize()
+        for rep in range(3):      # the second and third pass start from a known cost order
+            for k, u in enumerate(us):
+                tg = api.rt_target()
+                tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 0, cols[k].data_ptr()
+                sc.render_raw(api.make_frame(u, w, h, blend=False, stream=streams[k % 2].cuda_stream), tg)
+        torch.cuda.synchronize()
+        for k in range(len(us)):
+            assert np.array_equal(bits(cols[k].cpu().numpy()), bits(want[k])), (pipe, k)
+    sc.close()
