@@ -134,6 +134,20 @@ int rt_render(rt_scene *scene, const rt_frame *frame, const rt_target *target);
  * frames stay ordered), which a caller issuing one rt_render per frame on one stream cannot get.  Host-memory
  * targets are uploaded once before and downloaded once after the sequence. */
 int rt_render_sequence(rt_scene *scene, const rt_frame *frames, size_t n_frames, const rt_target *target);
+/* No counterpart in the reference.  For callers that cannot allocate device memory while they render -- code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc: rt_render with the one-kernel pipeline
+ * (RT_PIPELINE_MEGAKERNEL, whatever rt_scene_set_pipeline says) whose scratch buffer -- the per-tile cost map and start order
+ * of that kernel -- lives in a static device array of the library instead of a scene-owned allocation.  The call allocates
+ * and frees nothing, on the device or the host.  Pixels are identical to rt_render's.
+ *   - the target must be device memory (RT_MEM_DEVICE); sync = 0 or 1;
+ *   - one call covers at most RT_NOALLOC_MAX_TILES tiles of 16x16 pixels of the rows it renders (an 8K frame is 129 600);
+ *     more fails with RT_ELIMIT -- render the frame in bands (band_parts) or use rt_render;
+ *   - the array (1 MiB) is held by every GPU the library has created a scene on until the process ends, is shared by
+ *     ALL scenes and calls on that GPU and keeps the last call's contents (the library clears what must start at zero):
+ *     calls that overlap in time on one GPU race -- issue them on one stream, or order them yourself;
+ *   - the first call of a process on a device loads the kernels' code: make one call before starting a capture. */
+#define RT_NOALLOC_MAX_TILES (1u << 17)
+int rt_render_noalloc(rt_scene *scene, const rt_frame *frame, const rt_target *target);
 /* Number of rows a compact band buffer holds for this frame's band selection (whole strips; the last strip may
  * extend past `height`, those rows are never written). */
 uint32_t rt_band_row_count(const rt_frame *frame);

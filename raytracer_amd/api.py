@@ -28,7 +28,7 @@ RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = range(6)
 
 EXPORTED_SYMBOLS = [
-    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_band_row_count", "rt_scene_stats",
+    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_render_noalloc", "rt_band_row_count", "rt_scene_stats",
     "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free",
     # include/rt_camera.h (bound in glm_camera.py)
     "rt_vec3_normalize", "rt_camera_init", "rt_camera_set_view", "rt_camera_set_proj", "rt_camera_view_proj", "rt_camera_inv_view_proj", "rt_portal_difference_matrix", "rt_portal_ray",
@@ -99,6 +99,7 @@ def lib():
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.rt_skybox_set.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_frame), C.POINTER(rt_target)]
+        L.rt_render_noalloc.argtypes = [C.c_void_p, C.POINTER(rt_frame), C.POINTER(rt_target)]
         L.rt_render_sequence.argtypes = [C.c_void_p, C.POINTER(rt_frame), C.c_size_t, C.POINTER(rt_target)]
         L.rt_band_row_count.argtypes = [C.POINTER(rt_frame)]
         L.rt_band_row_count.restype = C.c_uint32
@@ -352,6 +353,10 @@ class Scene:
 
     def render_raw(self, frame: rt_frame, target: rt_target):
         _check(lib().rt_render(self._h, C.byref(frame), C.byref(target)))
+
+    def render_noalloc_raw(self, frame: rt_frame, target: rt_target):
+        """rt_render_noalloc: rt_render on a device-memory target without any allocation (static device scratch)."""
+        _check(lib().rt_render_noalloc(self._h, C.byref(frame), C.byref(target)))
 
     def render_sequence_raw(self, frames, target: rt_target):
         """Consecutive accumulation frames into one target in one call (frames: list of rt_frame)."""

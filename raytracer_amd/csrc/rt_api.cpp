@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -33,6 +34,38 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// rt_render_noalloc: the scratch of the one-kernel pipeline's cost-ordered start -- a cost per 16x16 tile measured by the
+// last launch, and the tile order sorted by it -- as a file-scope device array instead of a scene-owned allocation.  Each
+// device the library runs on holds its own copy (1 MiB) until the process ends.  The array's NAME is only a host-side
+// stand-in: its device address is asked for once per device (noalloc_setup, with that device current) and kept; host code
+// uses that pointer, never the name.
+// ------------------------------------------------------------------------------------------------------------------
+static __device__ __align__(256) uint32_t scratch[2u * RT_NOALLOC_MAX_TILES];   // [cost of tile | start order]
+
+namespace {
+constexpr int kMaxDevices = 64;
+struct NoAllocState {
+    uint32_t *ptr = nullptr;   // device address of this device's copy of `scratch`
+    uint64_t key = 0;          // frame geometry the order held by the array belongs to (0: none)
+    uint32_t age = 0;          // launches since the order was last rebuilt
+};
+NoAllocState g_noalloc[kMaxDevices];
+std::mutex g_noalloc_mutex;
+
+// Once per device, with that device current.
+int noalloc_setup(int dev) {
+    if (dev < 0 || dev >= kMaxDevices) return fail(RT_ELIMIT, "device %d is beyond the %d devices the library keeps scratch for", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (g_noalloc[dev].ptr) return RT_OK;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) return fail(RT_ENODEVICE, "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+    g_noalloc[dev].ptr = (uint32_t *)p;
+    return RT_OK;
+}
 }  // namespace
 
 struct rt_scene {
@@ -305,6 +338,7 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) s->n_cu = v;
         if (hipEventCreateWithFlags(&s->last_use, hipEventDisableTiming) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ENODEVICE, "cannot create an event"); }
+        if (int nrc = noalloc_setup(dev)) { rt_scene_destroy(s); return nrc; }   // (this device's scratch array of rt_render_noalloc)
     }
     *out = s;
     if (trace) fprintf(stderr, "rt_scene_create ms: reference check %.1f | upload %.1f | node records %.1f (%u) | triangle records %.1f\n", t_check, t_upload, t_flatten, nb.n_nodes, ms_since(t_phase));
@@ -739,6 +773,75 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
 int rt_render(rt_scene *s, const rt_frame *f, const rt_target *t) { return render_frames(s, f, 1, t); }
 
 int rt_render_sequence(rt_scene *s, const rt_frame *frames, size_t n_frames, const rt_target *t) { return render_frames(s, frames, n_frames, t); }
+
+// A variant of rt_render for callers that cannot allocate (see rt_hotpath.h): always the one-kernel pipeline, its cost map
+// and start order in this device's copy of `scratch`.  Nothing here allocates or frees: no hipMalloc / hipFree, no event or
+// stream creation, no growing host container.
+int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
+    if (!s || !f || !t) return fail(RT_EINVAL, "null argument");
+    if (!t->color) return fail(RT_EINVAL, "target colour plane is null");
+    if (t->memory != RT_MEM_DEVICE) return fail(RT_EINVAL, "rt_render_noalloc takes device-memory targets only (a host target needs staging buffers)");
+    if (f->width == 0 || f->height == 0 || f->width > 65536 || f->height > 65536) return fail(RT_EINVAL, "frame size %ux%u out of range", f->width, f->height);
+    if (f->band_parts == 0 || f->band_part >= f->band_parts || f->band_rows == 0) return fail(RT_EINVAL, "band selection %u/%u (rows %u) invalid", f->band_part, f->band_parts, f->band_rows);
+    if ((f->ndc_x == nullptr) != (f->ndc_y == nullptr)) return fail(RT_EINVAL, "ndc_x and ndc_y must be given together");
+    if ((unsigned long long)f->width * f->height >= 0xFFFFFFFFull) return fail(RT_ELIMIT, "frame has too many pixels");
+    if (f->accum_index == 0) return fail(RT_EINVAL, "accum_index must be >= 1");
+    if (f->compact_rows > 1) return fail(RT_EINVAL, "compact_rows must be 0 or 1");
+    const uint32_t n_local_rows = band_rows_of(f);
+    const size_t units = rt_render_units(f->width, n_local_rows);
+    if (units > RT_NOALLOC_MAX_TILES)
+        return fail(RT_ELIMIT, "rt_render_noalloc: this call covers %zu tiles of 16x16 pixels, the static scratch holds %u (use rt_render, or render the frame in bands)", units, RT_NOALLOC_MAX_TILES);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
+    if (s->device >= kMaxDevices || !g_noalloc[s->device].ptr) { if (int nrc = noalloc_setup(s->device)) return nrc; }
+    NoAllocState &na = g_noalloc[s->device];
+    hipStream_t st = (hipStream_t)f->stream;
+    if (s->used && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_use, 0));
+
+    RtLaunch L{};
+    L.u = f->u;
+    L.width = f->width; L.height = f->height; L.accum_index = f->accum_index; L.blend = f->blend ? 1u : 0u;
+    L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
+    L.n_local_rows = n_local_rows;
+    L.compact_rows = f->compact_rows;
+    L.near_first = s->order == RT_ORDER_NEAR_FIRST ? 1u : 0u;
+    L.n_cu = (uint32_t)s->n_cu;
+    L.sub_parts = 1; L.sub_part = 0;
+    L.counters = s->counting ? s->d_counters : nullptr;
+    if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
+    L.ndc_x = f->ndc_x; L.ndc_y = f->ndc_y;
+    L.color = t->color; L.depth = t->depth; L.hit_kind = t->hit_kind; L.hit_slot = t->hit_slot; L.hit_t = t->hit_t; L.n_rays = t->n_rays;
+    uint32_t rect[4];
+    const bool any = octree_screen_rect(s->d, f->u, f->width, f->height, rect);
+    hot_tiles(rect, any, f->band_rows, f->band_parts, L.hot);
+    if (units != 0) {
+        // The array keeps what the last call on this device left, whichever scene that was for.  An order is a permutation
+        // of the tiles of ONE frame geometry: it is used only by a call with the same geometry, and a call with another one
+        // starts from zeroed costs and the index order.
+        const uint32_t geo[7] = {f->width, f->height, f->band_rows, f->band_parts, f->band_part, n_local_rows, f->compact_rows};
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < sizeof geo; i++) { h ^= ((const unsigned char *)geo)[i]; h *= 1099511628211ull; }
+        if (h == 0) h = 1;
+        uint32_t *cost = na.ptr, *order = na.ptr + RT_NOALLOC_MAX_TILES;
+        const bool known = na.key == h;
+        if (!known) {
+            na.age = 0; na.key = 0;
+            HIP_TRY(hipMemsetAsync(cost, 0, units * sizeof(uint32_t), st));
+        }
+        L.cost = cost;
+        L.order = known ? order : nullptr;
+        L.order_next = (na.age % 8u == 0u) ? order : nullptr;
+        na.age++;
+        // (the key is set only once a launch that writes the order is enqueued: age 0 always does)
+        const char *kerr = nullptr;
+        if (rt_launch_render(s->d, L, nullptr, nullptr, st, &kerr, nullptr, nullptr) != 0) { na.key = 0; return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?"); }
+        na.key = h;
+    }
+    if (hipEventRecord(s->last_use, st) != hipSuccess) return fail(RT_ENODEVICE, "hipEventRecord failed");
+    s->last_stream = st; s->used = true;
+    if (t->sync) HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
 
 int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
