@@ -17,6 +17,11 @@ Fixtures
                           on triangles, and the reference's quad mesh assets/suzanne.obj (as triangulated by oracle.parse_obj)
   ref_ndc_640x512.npz     the interpolated NDC varying at the reference's own window size (not a power of two, so it
                           differs from the closed form): int32 ulp deltas, plus reference taps/colour for a band of rows
+  ref_ndc_1280x720.npz, ref_ndc_3840x2160.npz   the same at the two benchmark frame sizes (int16 deltas, bands of rows)
+  refsynth_<scene>_<view>.npz   reference records of the seeded synthetic scenes of raytracer_amd/scenes.py (100 000 primitives
+                          in a depth-8 octree; 1.28 M triangles in a depth-18 octree), stored WITHOUT the scene arrays: the
+                          tests rebuild the scene from its seed and check the SHA-256 digests kept here
+  refscene_deep.npz       a tree 26 levels deep (scenes.deep_test_scene), with its arrays
 """
 from __future__ import annotations
 
@@ -27,6 +32,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+import hashlib  # noqa: E402
 
 from oracle import oracle, refrun  # noqa: E402
 from raytracer_amd.camera import Camera, Portals, normalize  # noqa: E402
@@ -195,6 +202,8 @@ SCENE_VIEWS = {
     "suzanne_glass": dict(scene="suzanne5", cam=Camera(eye=(-1.3, 1.9, 6.4), at=(-2.5, 1.25, 4.1), aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=8)),
     "empty": dict(scene="empty", cam=Camera(aspect=1.0), size=(128, 128)),
     "suzanne_metal": dict(scene="suzanne2", cam=Camera(eye=(-4.6, 2.4, 5.9), at=(-2.5, 1.25, 4.1), aspect=1.0), size=(128, 128)),
+    # a tree 26 levels deep (the reference's own limit is 18): the traversal stacks of the deep-tree kernels
+    "deep": dict(scene="deep", cam=Camera(eye=(0.9, 4.2, 0.8), at=(0.0, 3.6, 0.0), fovy=0.8, aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=6)),
 }
 
 
@@ -204,12 +213,14 @@ def scene_fixtures():
     # no mesh at all: a root leaf without triangles in a box of zero size (never entered)
     empty = dict(vertices=np.zeros((1, 4), np.float32), normals=np.zeros((1, 4), np.float32), tri_refs=np.zeros((1, 4), np.uint32), nodes=np.zeros(2, np.uint32),
                  bounds_min=np.zeros(3, np.float32), bounds_max=np.zeros(3, np.float32))
-    built = {"materials": materials_scene(), "suzanne5": suzanne_scene(5), "suzanne2": suzanne_scene(2), "empty": empty}
+    from raytracer_amd import scenes
+    built = {"materials": materials_scene, "suzanne5": lambda: suzanne_scene(5), "suzanne2": lambda: suzanne_scene(2), "empty": lambda: empty,
+             "deep": lambda: scenes.deep_test_scene().as_dict()}
     only = sys.argv[2:] if len(sys.argv) > 2 else None
     for name, v in SCENE_VIEWS.items():
         if only and name not in only:
             continue
-        scene = built[v["scene"]]
+        scene = built[v["scene"]]()
         w, h = v["size"]
         u = Uniforms.from_camera(v["cam"], **v.get("kw", {})).pack()
         rec = reference_record(scene, u, w, h, sky)
@@ -218,6 +229,59 @@ def scene_fixtures():
         tri = rec["kind"] == 2
         print(name, w, h, "kinds", np.bincount(rec["kind"].ravel(), minlength=6), "materials of primary triangle hits", np.unique(np.asarray(scene["tri_refs"]).reshape(-1, 4)[rec["slot"][tri], 3]).tolist(),
               "max segments", int(rec["nrays"].max()), os.path.getsize(os.path.join(GOLDEN, f"refscene_{name}.npz")))
+
+
+def scene_digests(scene: dict) -> dict:
+    """SHA-256 of the bytes of each scene array (vertices, normals, tri_refs, nodes as the octree builders return them)."""
+    out = {}
+    for k, dt in (("vertices", np.float32), ("normals", np.float32), ("tri_refs", np.uint32), ("nodes", np.uint32), ("bounds_min", np.float32), ("bounds_max", np.float32)):
+        out[k] = hashlib.sha256(np.ascontiguousarray(scene[k], dt).tobytes()).hexdigest()
+    return out
+
+
+# Views of the synthetic scenes (primitives fill the cube |x|,|z| <= 4 (3), -1 (0) <= y <= 7 (6) around (0, 3, 0)): the
+# benchmark's camera, which stands inside the cube; one from outside; one from the centre with the shorter path.
+SYNTH_VIEWS = {
+    "bench": dict(cam=Camera(aspect=1.0), size=(256, 256), kw=dict(max_recursion_limit=5)),
+    "outside": dict(cam=Camera(eye=(10.0, 7.0, 10.0), at=(0.0, 3.0, 0.0), aspect=2.0), size=(256, 128), kw=dict(max_recursion_limit=5, time=0.25)),
+    "centre": dict(cam=Camera(eye=(0.0, 3.0, 0.0), at=(1.0, 2.6, 0.3), aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=2)),
+}
+
+
+def synthetic_fixtures():
+    """refsynth_<scene>_<view>.npz: the reference shader on the two seeded synthetic scenes of raytracer_amd/scenes.py."""
+    from raytracer_amd import scenes
+    sky = fixture_sky()
+    for name, build in (("100k", scenes.synthetic_100k), ("1m", scenes.synthetic_1m)):
+        oc = build()
+        scene = oc.as_dict()
+        dig = scene_digests(scene)
+        for vname, v in SYNTH_VIEWS.items():
+            w, h = v["size"]
+            u = Uniforms.from_camera(v["cam"], **v.get("kw", {})).pack()
+            rec = reference_record(scene, u, w, h, sky)
+            rec.update({"sha256_" + k: np.array(d) for k, d in dig.items()})
+            rec["n_ref"], rec["n_words"], rec["max_depth"] = np.int64(len(scene["tri_refs"])), np.int64(len(scene["nodes"])), np.int64(oc.max_depth)
+            path = os.path.join(GOLDEN, f"refsynth_{name}_{vname}.npz")
+            np.savez_compressed(path, **rec)
+            print("synthetic", name, vname, w, h, "kinds", np.bincount(rec["kind"].ravel(), minlength=6), "segments", np.bincount(rec["nrays"].ravel()), os.path.getsize(path))
+
+
+def ndc_fixture(w: int, h: int, rows, **kw):
+    """ref_ndc_<w>x<h>.npz: the rasteriser's interpolated NDC as ulp deltas against the closed form, and the reference's
+    record of the bunny scene for a band of rows rendered with it."""
+    scene, sky = bunny_scene(), fixture_sky()
+    nx, ny = capture_ndc(w, h)
+    cx, cy = closed_form_ndc(w, h)
+    dx, dy = ulp_delta(nx, cx), ulp_delta(ny, cy)
+    assert np.abs(dx).max() < 2 ** 15 and np.abs(dy).max() < 2 ** 15
+    assert np.array_equal(apply_ulp_delta(cx, dx).view(np.uint32), nx.view(np.uint32)) and np.array_equal(apply_ulp_delta(cy, dy).view(np.uint32), ny.view(np.uint32))
+    u = Uniforms.from_camera(Camera(aspect=w / h), **kw).pack()
+    rec = reference_record(scene, u, w, h, sky, rows=rows)
+    rec["ndc_dx"], rec["ndc_dy"] = dx.astype(np.int16), dy.astype(np.int16)
+    path = os.path.join(GOLDEN, f"ref_ndc_{w}x{h}.npz")
+    np.savez_compressed(path, **rec)
+    print("ndc %dx%d: x differs on %.1f%% of pixels, y on %.1f%%; kinds in the band %s; %d bytes" % (w, h, 100 * (dx != 0).mean(), 100 * (dy != 0).mean(), np.bincount(rec["kind"].ravel(), minlength=6), os.path.getsize(path)))
 
 
 def sky_size_fixture():
@@ -254,6 +318,15 @@ def main():
         refrun.build()
         assert refrun.available(), "needs /root/reference and the llvmpipe runner"
         accum8_fixture()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] in ("synthetic", "ndc"):
+        refrun.build()
+        assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+        if sys.argv[1] == "synthetic":
+            synthetic_fixtures()
+        else:
+            ndc_fixture(1280, 720, (440, 504), max_recursion_limit=5)
+            ndc_fixture(3840, 2160, (1400, 1432), max_recursion_limit=2)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sky":
         refrun.build()
@@ -311,6 +384,9 @@ def main():
     scene_fixtures()
     sky_size_fixture()
     accum8_fixture()
+    synthetic_fixtures()
+    ndc_fixture(1280, 720, (440, 504), max_recursion_limit=5)
+    ndc_fixture(3840, 2160, (1400, 1432), max_recursion_limit=2)
     total = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
     print("fixtures total bytes:", total)
 

@@ -135,3 +135,26 @@ def small_test_scene(seed: int = 3, n: int = 60) -> api.Octree:
     """A few dozen primitives near the default camera's view: fast to build, exercises every material."""
     meshes = synthetic_primitives(n, seed=seed, sphere_subdiv=1, extent=1.5, centre=(0.0, 1.5, 0.0), size_range=(0.1, 0.35), materials=(0, 1, 2, 3, 4, 5, 6))
     return api.Octree(meshes, 10, 10, 6, 6)
+
+
+def deep_test_meshes(seed: int = 5, n: int = 1500, far: float = 3.0e5, centre=(0.0, 3.6, 0.0)):
+    """A cluster of `n` small triangles around `centre` (above the shader's big middle sphere) plus two tiny triangles
+    `far` units out, which stretch the root box so much that the cluster's leaves lie about 26 levels down.  Materials 1,
+    5 and 2 (metal, glass, diffuse)."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-0.25, 0.25, size=(n, 3)) + np.asarray(centre, np.float64)
+    tri = c[:, None, :] + rng.normal(0.0, 0.012, size=(n, 3, 3))
+    meshes = []
+    for k, m in enumerate((1, 5, 2)):
+        pos = tri[k::3].reshape(-1, 3)
+        if k == 0:
+            f = float(far)
+            pos = np.concatenate([pos, [[-f, -f, -f], [-f + 1, -f, -f], [-f, -f + 1, -f], [f, f, f], [f - 1, f, f], [f, f - 1, f]]])
+        meshes.append(api.Mesh(positions=pos.astype(np.float32), faces=np.arange(len(pos), dtype=np.uint32).reshape(-1, 3), material_id=m))
+    return meshes
+
+
+def deep_test_scene(depth_limit: int = 30, device: int | None = None) -> api.Octree:
+    """A tree deeper than the reference's default limit of 18 (deep_test_meshes), for the traversal kernels built for
+    deep trees."""
+    return api.Octree(deep_test_meshes(), depth_limit, 10, 6, 6, device=device)

@@ -12,7 +12,7 @@ from oracle import oracle
 from oracle.gen_fixtures import apply_ulp_delta, closed_form_ndc, bunny_scene
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_accum8.npz", "ref_math.npz", "ref_ndc_640x512.npz", "ref_sky_sizes.npz"))
+VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_accum8.npz", "ref_math.npz", "ref_sky_sizes.npz") and not os.path.basename(f).startswith("ref_ndc_"))
 
 
 def bits(a):
@@ -113,6 +113,50 @@ def test_oracle_with_interpolated_ndc_table(scene):
     # and the closed form does NOT reproduce it (the seed hashes the NDC bits), which is why the table exists
     o2 = oracle.OracleScene(scene, z["sky"]).render(z["uniforms"], w, h, rows=rows)
     assert not np.array_equal(bits(o2["seed"][rows[0]:rows[1]]), bits(z["seed"]))
+
+
+@pytest.mark.parametrize("size", [(1280, 720), (3840, 2160)])
+def test_oracle_with_interpolated_ndc_at_the_benchmark_frame_sizes(scene, size):
+    """The same at 1280x720 and 3840x2160, where x AND y differ from the closed form on most pixels."""
+    w, h = size
+    z = np.load(os.path.join(GOLDEN, f"ref_ndc_{w}x{h}.npz"))
+    cx, cy = closed_form_ndc(w, h)
+    nx, ny = apply_ulp_delta(cx, z["ndc_dx"]), apply_ulp_delta(cy, z["ndc_dy"])
+    assert (z["ndc_dx"] != 0).mean() > 0.5 and (z["ndc_dy"] != 0).mean() > 0.5
+    rows = tuple(int(v) for v in z["rows"])
+    o = oracle.OracleScene(scene, z["sky"]).render(z["uniforms"], w, h, rows=rows, ndc=(nx, ny))
+    check_record(o, z, rows)
+
+
+SYNTH_FILES = sorted(glob.glob(os.path.join(GOLDEN, "refsynth_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def synthetic_scenes():
+    """The two seeded synthetic scenes, built once by the host builder (the fixtures hold digests, not arrays)."""
+    from raytracer_amd import scenes
+    return {"100k": scenes.synthetic_100k().as_dict(), "1m": scenes.synthetic_1m().as_dict()}
+
+
+@pytest.mark.parametrize("path", SYNTH_FILES, ids=[os.path.basename(p)[9:-4] for p in SYNTH_FILES])
+def test_oracle_matches_reference_on_the_synthetic_scenes(synthetic_scenes, path):
+    from oracle.gen_fixtures import scene_digests
+    z = np.load(path)
+    scene = synthetic_scenes[os.path.basename(path).split("_")[1]]
+    for k, v in scene_digests(scene).items():
+        assert str(z["sha256_" + k]) == v, k
+    w, h = (int(v) for v in z["size"])
+    o = oracle.OracleScene(scene, z["sky"]).render(z["uniforms"], w, h)
+    check_record(o, z)
+
+
+def test_synthetic_fixture_coverage():
+    assert len(SYNTH_FILES) == 6
+    for p in SYNTH_FILES:
+        z = np.load(p)
+        assert (z["kind"] == 2).sum() > 900 and "scene_vertices" not in z.files
+    z = np.load(os.path.join(GOLDEN, "refsynth_1m_bench.npz"))
+    assert int(z["n_ref"]) > 8_000_000 and int(z["nrays"].max()) == 5 and (z["nrays"] == 5).mean() > 0.5
 
 
 def test_oracle_math_matches_llvmpipe():
