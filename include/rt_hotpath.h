@@ -103,6 +103,11 @@ typedef struct rt_stats {
     uint64_t child_box_tests;      /* child RayAABB calls (frag:504) */
     uint64_t triangle_hits_shaded; /* segments whose closest hit is a triangle (frag:541-556) */
     uint64_t rays_entering_octree; /* segments passing the root box test (frag:449) */
+    uint64_t sphere_tests;         /* RaySphere evaluations actually executed (the shader runs 84 per segment, frag:439-445;
+                                      the kernels skip spheres a ray provably cannot be accepted by) */
+    uint64_t node_pops_from_lds;   /* of node_pops: visits served from the workgroup's LDS copy of the tree's top three levels */
+    uint64_t exact_fallbacks;      /* RT_ORDER_NEAR_FIRST_EXACT: segments re-traversed in the reference's order */
+    uint64_t exact_candidate_checks; /* RT_ORDER_NEAR_FIRST_EXACT: boxes of earlier references of the hit triangle tested */
 } rt_stats;
 
 /* Library / device ------------------------------------------------------------------------------------------ */
@@ -195,9 +200,17 @@ int rt_scene_set_sequence_batch(rt_scene *scene, int max_frames);
  * closest hit is searched over a different set of nodes, so a result can differ from the shader's where floating-point
  * box and triangle tests disagree about a hit on a box boundary, and where two references or two triangles give exactly
  * the same distance the other one may be reported (same distance, the same triangle when the references are duplicates).
- * This mode is held to the tolerance bar -- colour within 1/255 on at least 99.9 % of the pixels -- not to bit identity. */
+ * This mode is held to the tolerance bar -- colour within 1/255 on at least 99.9 % of the pixels -- not to bit identity.
+ * RT_ORDER_NEAR_FIRST_EXACT: the children nearest first AND the reference's result: among the references of the hit triangle
+ * the one the shader's traversal meets first is reported (every node carries its rank in the shader's visiting order), and a
+ * ray for which that cannot be decided locally -- an earlier reference of the triangle lies in a box the ray enters behind the
+ * hit point, or another triangle is hit at the bit-equal distance -- is traversed again in the shader's own order.  Every
+ * bit-exactness test of this repository also runs in this mode; what it does not cover by construction is a ray whose float
+ * box and triangle tests disagree about a hit exactly on a box face (see the kernels' comment).  Wavefront and persistent
+ * pipelines; the one-kernel pipeline runs the reference's order in this mode. */
 #define RT_ORDER_REFERENCE 0
 #define RT_ORDER_NEAR_FIRST 1
+#define RT_ORDER_NEAR_FIRST_EXACT 2
 int rt_scene_set_traversal_order(rt_scene *scene, int order);
 int rt_scene_destroy(rt_scene *scene);
 

@@ -62,7 +62,8 @@ class rt_target(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_pops", C.c_uint64), ("triangle_tests", C.c_uint64), ("child_box_tests", C.c_uint64),
-                ("triangle_hits_shaded", C.c_uint64), ("rays_entering_octree", C.c_uint64)]
+                ("triangle_hits_shaded", C.c_uint64), ("rays_entering_octree", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("node_pops_from_lds", C.c_uint64), ("exact_fallbacks", C.c_uint64), ("exact_candidate_checks", C.c_uint64)]
 
 
 class rt_mesh(C.Structure):
@@ -340,8 +341,9 @@ class Scene:
         _check(lib().rt_scene_set_sequence_batch(self._h, max_frames))
 
     def set_traversal_order(self, order: str):
-        """'reference' (default: bit-identical to the shader) or 'near_first' (faster, held to the colour tolerance only)."""
-        _check(lib().rt_scene_set_traversal_order(self._h, {"reference": 0, "near_first": 1}[order]))
+        """'reference' (default: the shader's own child order), 'near_first' (faster, held to the colour tolerance only) or
+        'near_first_exact' (near first, with the shader's result: see rt_hotpath.h)."""
+        _check(lib().rt_scene_set_traversal_order(self._h, {"reference": 0, "near_first": 1, "near_first_exact": 2}[order]))
 
     def set_subframes(self, n: int):
         _check(lib().rt_scene_set_subframes(self._h, n))

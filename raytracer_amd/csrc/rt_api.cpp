@@ -71,7 +71,7 @@ int noalloc_setup(int dev) {
 struct rt_scene {
     int device = 0;
     RtDeviceScene d{};
-    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_sky = nullptr;
+    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_dup = nullptr, *d_sky = nullptr;
     unsigned long long *d_counters = nullptr;
     bool counting = false;
     // staging for host-memory targets
@@ -111,11 +111,17 @@ struct rt_scene {
     // pairs around a call's launches, read back without blocking at a later call) and uses the fastest for the workload
     // at hand; the others are measured again now and then.
     struct Tuner {
-        uint64_t key = 0;                  // frame size / recursion limit / band split the measurements belong to
-        double ms[3] = {-1.0, -1.0, -1.0};  // per-frame time of each pipeline (< 0: not measured yet)
-        uint32_t seen[3] = {0, 0, 0};       // measurements taken (the first one of a pipeline is a warm-up and is dropped)
-        uint32_t calls = 0;
+        // single frames and sequences are different workloads for the one-kernel pipeline (a sequence is traced several
+        // frames per launch): each kind of call keeps measurements of its own, so that alternating between them loses none
+        struct Table {
+            uint64_t key = 0;                   // frame size / recursion limit / band split the measurements belong to
+            double ms[3] = {-1.0, -1.0, -1.0};  // per-frame time of each pipeline (< 0: not measured yet)
+            uint32_t seen[3] = {0, 0, 0};       // measurements taken (the first one of a pipeline is a warm-up and is dropped)
+            uint32_t calls = 0;
+        } tab[2];
+        int cur = 0;                       // table of the call at hand (0: one frame, 1: a sequence)
         int pending = -1;                  // pipeline of the measurement in flight
+        int pending_tab = 0;
         uint32_t pending_frames = 0;
         bool look_again = false;            // the periodic second look at the slower pipelines is due
         bool in_split = false;              // inside a long sequence that is issued as probe part + rest
@@ -321,15 +327,16 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     t_flatten = ms_since(t_phase); t_phase = now();
     if (n_ref) {
         hipError_t e = hipMalloc(&s->d_tris, n_ref * sizeof(RtTriRec));
-        if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes, (RtTriRec *)s->d_tris);
+        if (e == hipSuccess) e = hipMalloc(&s->d_dup, n_ref * sizeof(uint32_t));
+        if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes, (RtTriRec *)s->d_tris, (uint32_t *)s->d_dup);
         if (e != hipSuccess) { rt_scene_destroy(s); return fail(e == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "triangle records: %s", hipGetErrorString(e)); }
     }
-    if (hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_counters, 0, 64) != hipSuccess) {
+    if (hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_counters, 0, 128) != hipSuccess) {
         rt_scene_destroy(s);
         return fail(RT_ENOMEM, "cannot allocate counters");
     }
     s->d.vertices = (const float *)s->d_vertices; s->d.normals = (const float *)s->d_normals; s->d.tri_refs = (const uint32_t *)s->d_refs;
-    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.sky = nullptr;
+    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.sky = nullptr;
     s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = nb.n_nodes;
     s->d.sky_w = s->d.sky_h = 0;
     for (int k = 0; k < 3; k++) { s->d.bounds_min[k] = bounds_min[k]; s->d.bounds_max[k] = bounds_max[k]; }
@@ -374,14 +381,15 @@ int rt_scene_set_pipeline(rt_scene *s, int pipeline) {
 int rt_scene_pipeline_state(rt_scene *s, int *selected, double ms_per_frame[3]) {
     if (!s || !selected || !ms_per_frame) return fail(RT_EINVAL, "null argument");
     int best = -1;
-    for (int p = 0; p < 3; p++) { ms_per_frame[p] = s->tuner.ms[p]; if (s->tuner.ms[p] >= 0.0 && (best < 0 || s->tuner.ms[p] < s->tuner.ms[best])) best = p; }
+    const rt_scene::Tuner::Table &tb = s->tuner.tab[s->tuner.cur];   // (of the kind of call made last)
+    for (int p = 0; p < 3; p++) { ms_per_frame[p] = tb.ms[p]; if (tb.ms[p] >= 0.0 && (best < 0 || tb.ms[p] < tb.ms[best])) best = p; }
     *selected = s->pipeline != RT_PIPELINE_AUTO ? s->pipeline : (best >= 0 ? best : RT_PIPELINE_MEGAKERNEL);
     return RT_OK;
 }
 
 int rt_scene_set_traversal_order(rt_scene *s, int order) {
     if (!s) return fail(RT_EINVAL, "scene is null");
-    if (order != RT_ORDER_REFERENCE && order != RT_ORDER_NEAR_FIRST) return fail(RT_EINVAL, "unknown traversal order %d", order);
+    if (order != RT_ORDER_REFERENCE && order != RT_ORDER_NEAR_FIRST && order != RT_ORDER_NEAR_FIRST_EXACT) return fail(RT_EINVAL, "unknown traversal order %d", order);
     s->order = order;
     return RT_OK;
 }
@@ -455,10 +463,11 @@ int rt_scene_stats(rt_scene *s, rt_stats *out) {
     if (!s || !out) return fail(RT_EINVAL, "null argument");
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(RT_ENODEVICE, "cannot select HIP device %d", s->device);
-    unsigned long long c[8];
+    unsigned long long c[16];
     HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c[0]; out->node_pops = c[1]; out->triangle_tests = c[2]; out->child_box_tests = c[3];
-    out->triangle_hits_shaded = c[4]; out->rays_entering_octree = c[5];
+    out->triangle_hits_shaded = c[4]; out->rays_entering_octree = c[5]; out->sphere_tests = c[6];
+    out->node_pops_from_lds = c[7]; out->exact_fallbacks = c[8]; out->exact_candidate_checks = c[9];
     return RT_OK;
 }
 
@@ -471,31 +480,34 @@ static uint32_t band_rows_of(const rt_frame *f) {
 uint32_t rt_band_row_count(const rt_frame *f) { return band_rows_of(f); }
 
 // RT_PIPELINE_AUTO: collects a finished measurement, then picks the pipeline of this call and says whether to time it.
-static int tuner_choose(rt_scene *s, uint64_t key, bool *measure) {
-    rt_scene::Tuner &t = s->tuner;
+static int tuner_choose(rt_scene *s, uint64_t key, bool sequence, bool *measure) {
+    rt_scene::Tuner &tn = s->tuner;
     *measure = false;
-    if (!t.a && (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess)) { t.a = t.b = nullptr; return RT_PIPELINE_MEGAKERNEL; }
-    if (t.pending >= 0 && hipEventQuery(t.b) == hipSuccess) {
+    if (!tn.a && (hipEventCreate(&tn.a) != hipSuccess || hipEventCreate(&tn.b) != hipSuccess)) { tn.a = tn.b = nullptr; return RT_PIPELINE_MEGAKERNEL; }
+    if (tn.pending >= 0 && hipEventQuery(tn.b) == hipSuccess) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && t.pending_frames > 0) {
-            const double per_frame = (double)ms / t.pending_frames;
-            const int p = t.pending;
-            if (t.seen[p]++ > 0) t.ms[p] = t.ms[p] < 0.0 ? per_frame : 0.5 * (t.ms[p] + per_frame);
+        if (hipEventElapsedTime(&ms, tn.a, tn.b) == hipSuccess && tn.pending_frames > 0) {
+            const double per_frame = (double)ms / tn.pending_frames;
+            const int p = tn.pending;
+            rt_scene::Tuner::Table &pt = tn.tab[tn.pending_tab];
+            if (pt.seen[p]++ > 0) pt.ms[p] = pt.ms[p] < 0.0 ? per_frame : 0.5 * (pt.ms[p] + per_frame);
         }
-        t.pending = -1;
+        tn.pending = -1;
     }
-    if (key != t.key) { t.key = key; for (int p = 0; p < 3; p++) { t.ms[p] = -1.0; t.seen[p] = 0; } t.calls = 0; }
+    tn.cur = sequence ? 1 : 0;
+    rt_scene::Tuner::Table &t = tn.tab[tn.cur];
+    if (key != t.key) { t.key = key; for (int p = 0; p < 3; p++) { t.ms[p] = -1.0; t.seen[p] = 0; } t.calls = 0; if (tn.pending_tab == tn.cur) tn.pending = -1; }
     t.calls++;
     int best = -1;
     for (int p = 0; p < 3; p++) if (t.ms[p] >= 0.0 && (best < 0 || t.ms[p] < t.ms[best])) best = p;
     int choice = best >= 0 ? best : RT_PIPELINE_MEGAKERNEL;
-    if (t.calls % 64u == 0u) t.look_again = true;
-    if (t.pending < 0) {
+    if (t.calls % 64u == 0u) tn.look_again = true;
+    if (tn.pending < 0) {
         *measure = true;
-        if (t.no_explore) return choice;
+        if (tn.no_explore) return choice;
         for (int p = 0; p < 3; p++) if (t.ms[p] < 0.0) return p;                              // something still unknown: try it
-        if (t.look_again) {                                                                   // look at the others again now and then
-            t.look_again = false;
+        if (tn.look_again) {                                                                   // look at the others again now and then
+            tn.look_again = false;
             choice = (best + 1 + (int)((t.calls / 64u) % 2u)) % 3;
         }
     }
@@ -558,17 +570,17 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
     L.n_local_rows = band_rows_of(f);   // rows owned by this part: whole strips, the last one clipped by the kernel
     L.compact_rows = f->compact_rows;
-    L.near_first = s->order == RT_ORDER_NEAR_FIRST ? 1u : 0u;
+    L.near_first = (uint32_t)s->order;
     L.n_cu = (uint32_t)s->n_cu;
     L.counters = s->counting ? s->d_counters : nullptr;
-    if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
+    if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 128, st));
 
     L.sub_parts = 1; L.sub_part = 0;
     int pipeline = s->pipeline;
     bool measure = false;
     if (pipeline == RT_PIPELINE_AUTO) {
-        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^ (uint64_t)(n_frames > 1 ? 2 : 0) ^ (uint64_t)(s->order ? 4 : 0);
-        pipeline = tuner_choose(s, key + 1, &measure);
+        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^ (uint64_t)(s->order ? 4 : 0);
+        pipeline = tuner_choose(s, key + 1, n_frames > 1, &measure);
     }
     bool wavefront = pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
     bool persistent = pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
@@ -593,7 +605,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
                     // (about 112 bytes per pixel.)  Under automatic selection a pipeline that cannot get its workspace is
                     // given up for this workload instead of failing the render: the one-kernel pipeline needs none.
                     if (s->pipeline != RT_PIPELINE_AUTO) return wrc;
-                    s->tuner.ms[RT_PIPELINE_WAVEFRONT] = 1e30; s->tuner.seen[RT_PIPELINE_WAVEFRONT] = 2;
+                    s->tuner.tab[s->tuner.cur].ms[RT_PIPELINE_WAVEFRONT] = 1e30; s->tuner.tab[s->tuner.cur].seen[RT_PIPELINE_WAVEFRONT] = 2;
                     (void)hipGetLastError();   // (the failed allocation's error is handled here)
                     wavefront = false; measure = false; pipeline = RT_PIPELINE_MEGAKERNEL; K = 1;
                     break;
@@ -724,7 +736,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         if (hipEventRecord(s->tuner.a, st) != hipSuccess) return 1;
         const int rc = launch_frames(L0, kerr);
         if (rc != 0 || hipEventRecord(s->tuner.b, st) != hipSuccess) return rc != 0 ? rc : 1;
-        s->tuner.pending = pipeline; s->tuner.pending_frames = (uint32_t)n_frames;
+        s->tuner.pending = pipeline; s->tuner.pending_tab = s->tuner.cur; s->tuner.pending_frames = (uint32_t)n_frames;
         return 0;
     };
     const size_t px = (size_t)f->width * f->height;                                            // ndc planes
@@ -804,11 +816,11 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
     L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
     L.n_local_rows = n_local_rows;
     L.compact_rows = f->compact_rows;
-    L.near_first = s->order == RT_ORDER_NEAR_FIRST ? 1u : 0u;
+    L.near_first = (uint32_t)s->order;
     L.n_cu = (uint32_t)s->n_cu;
     L.sub_parts = 1; L.sub_part = 0;
     L.counters = s->counting ? s->d_counters : nullptr;
-    if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, st));
+    if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 128, st));
     L.ndc_x = f->ndc_x; L.ndc_y = f->ndc_y;
     L.color = t->color; L.depth = t->depth; L.hit_kind = t->hit_kind; L.hit_slot = t->hit_slot; L.hit_t = t->hit_t; L.n_rays = t->n_rays;
     uint32_t rect[4];
@@ -846,7 +858,7 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
 int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     DeviceGuard guard(s->device);
-    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_sky, s->d_counters};
+    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_dup, s->d_sky, s->d_counters};
     for (void *q : p) if (q) (void)hipFree(q);
     free_staging(s);
     for (rt_scene::Sub &sb : s->sub) {

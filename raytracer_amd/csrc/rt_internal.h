@@ -18,12 +18,16 @@ struct alignas(64) RtNodeRec {
     uint32_t info;        // tri_count << 16 | child_mask << 8 | child_count  (reference word 0)
     uint32_t tri_start;   // reference word 1
     uint32_t first_child; // record index of the child in octant 0 (undefined when child_count == 0)
-    uint32_t reserved;
+    uint32_t rank;        // position of the node in the order in which the reference shader's traversal meets the nodes of the
+                          // whole tree: depth first, a node before its children, children in DESCENDING octant order (frag:456,489-513)
     float lo[3];
     float mid[3];
     float hi[3];
-    uint32_t pad[3];
+    uint32_t parent;      // record index of the parent | octant << 24 (RT_NO_PARENT for the root)
+    uint32_t first_id;    // a leaf: RtTriRec::dup_first of its first triangle (the one carried in the box fields)
+    uint32_t pad;
 };
+#define RT_NO_PARENT 0xFFFFFFFFu
 static_assert(sizeof(RtNodeRec) == 64, "node record must be one 64-byte line");
 #define RT_MAX_SUBFRAMES 8
 #define RT_MAX_NODE_RECORDS (1u << 24)   // a traversal stack entry packs a record index into 24 bits
@@ -31,10 +35,15 @@ static_assert(sizeof(RtNodeRec) == 64, "node record must be one 64-byte line");
 // One triangle reference prepared for Moeller-Trumbore: first vertex and the two edges, computed once per scene with
 // the same IEEE subtractions the shader performs per test (frag:256-257), so a test needs three 16-byte loads
 // instead of an index load followed by three dependent vertex gathers.
+// The same triangle is referenced from every leaf it overlaps (Octree.cpp:146-170).  The references of one triangle --
+// equal (i0, i1, i2, material) -- form a RUN in an array sorted by triangle and then by the rank of the node that holds
+// the reference: dup_first / dup_pos are the run's first position and this reference's own position in that array, so the
+// references of the same triangle that the reference traversal would meet EARLIER than this one are the positions
+// [dup_first, dup_pos), and dup_first identifies the triangle.
 struct alignas(16) RtTriRec {
     float v1[3]; float e1x;
     float e1y, e1z, e2x, e2y;
-    float e2z; uint32_t pad[3];
+    float e2z; uint32_t dup_first, dup_pos, pad;
 };
 static_assert(sizeof(RtTriRec) == 48, "triangle record is three 16-byte quads");
 
@@ -44,6 +53,7 @@ struct RtDeviceScene {
     const uint32_t *tri_refs;  // [n_ref][4]
     const RtNodeRec *nodes;    // [n_nodes]
     const RtTriRec *tris;      // [n_ref]
+    const uint32_t *dup_parent; // [n_ref]: by position in the sorted reference array (see RtTriRec): `parent` word of the node holding that reference
     const uint8_t *sky;        // [6][sky_h][sky_w][4] or null
     uint32_t n_vert, n_ref, n_nodes;
     int32_t sky_w, sky_h;
@@ -57,7 +67,7 @@ struct RtLaunch {
     uint32_t band_rows, band_parts, band_part, n_local_rows;
     uint32_t compact_rows;
     uint32_t n_cu;                  // compute units of the device (sizes the persistent kernels' grids; 0: 256)
-    uint32_t near_first;            // children of an octree node are visited nearest first instead of in the reference's order
+    uint32_t near_first;            // RT_ORDER_*: 0 the reference's child order, 1 nearest first, 2 nearest first with the reference's result (see Exact)
     uint32_t sub_parts, sub_part;   // this launch renders sub-frame sub_part of sub_parts of the caller's band (1, 0: all of it)
     uint32_t hot[4];                // tile rectangle (x0, y0, x1, y1 inclusive, 16x16 tiles of the local rows) where the octree projects to; x1 < x0: none
     // Cost-ordered start of the one-lane-per-pixel kernel (all three null: index order).  order: permutation of the
@@ -68,7 +78,7 @@ struct RtLaunch {
     const float *ndc_x, *ndc_y;
     float *color, *depth, *hit_t;
     uint32_t *hit_kind, *hit_slot, *n_rays;
-    unsigned long long *counters;   // 8 x u64 or null
+    unsigned long long *counters;   // 16 x u64 or null
 };
 
 // Device workspace of the per-depth wavefront pipeline.  Path segments of one depth are addressed by slot; the
@@ -129,8 +139,10 @@ size_t rt_pool_bytes();   // size of the persistent path kernel's tile-counter b
 #define RT_NODE_ERROR_TOO_MANY 101u
 #define RT_NODE_ERROR_RECORD_LIMIT 102u
 struct RtNodeBuild { RtNodeRec *nodes; uint32_t n_nodes, max_depth, error, error_word; int hip_error; };
+#define RT_TOP_RECORDS 73u   // records of the three top levels (1 + 8 + 64): the part of the tree every entering ray visits
 int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3], RtNodeBuild *out);
-int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris);
+// dup_parent: n_ref words (see RtDeviceScene).
+int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent);
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
 // pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:

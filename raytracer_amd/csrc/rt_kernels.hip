@@ -280,7 +280,7 @@ __constant__ SphereGrid c_sphere_grid = make_sphere_grid();
 struct Ray { f3 pos, dir, inv; };
 struct Hit { bool has_hit; f3 position, normal; uint32_t material_id, portal_id; };
 struct PrimaryTap { uint32_t kind, slot; float t; };
-struct Counters { uint32_t rays, pops, tri_tests, box_tests, tri_shaded, entered; };
+struct Counters { uint32_t rays, pops, tri_tests, box_tests, tri_shaded, entered, sph_tests, lds_pops, fallbacks, cand_checks; };
 
 // frag:417-425
 DEVI bool ray_aabb(const Ray &r, f3 lo, f3 hi, float closest) {
@@ -357,8 +357,9 @@ DEVI SphereMask sphere_candidates(const SphereGrid *g, const Ray &r) {
 // The sphere loop of frag:439-445 over the candidate set, in index order.  PRIMARY: tab holds (oc.xyz, c) of a shared
 // ray origin; otherwise (centre.xyz, radius).
 template <bool PRIMARY>
-DEVI void intersect_spheres_culled(const SphereLds *lds, const Ray &r, float &closest, uint32_t &closest_i) {
+DEVI void intersect_spheres_culled(const SphereLds *lds, const Ray &r, float &closest, uint32_t &closest_i, uint32_t *n_tests = nullptr) {
     const SphereMask m = sphere_candidates(&lds->grid, r);
+    if (n_tests) *n_tests += (uint32_t)(__popc(m.w[0]) + __popc(m.w[1]) + __popc(m.w[2]));   // sphere tests actually executed
 #pragma unroll
     for (uint32_t w = 0; w < 3; w++) {
         uint32_t bits = m.w[w];
@@ -398,12 +399,13 @@ DEVI void intersect_spheres_culled(const SphereLds *lds, const Ray &r, float &cl
 }
 
 // frag:255-281 on a prepared triangle record (first vertex and the two edges)
-struct TriData { float4 q0, q1; float e2z; };
+struct TriData { float4 q0, q1; float e2z; uint32_t id; };   // id: RtTriRec::dup_first, which identifies the triangle behind the reference
 DEVI TriData load_triangle(const RtTriRec *tr) {
     TriData d;
     d.q0 = *reinterpret_cast<const float4 *>(tr);
     d.q1 = *(reinterpret_cast<const float4 *>(tr) + 1);
-    d.e2z = tr->e2z;
+    const uint2 q2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const float4 *>(tr) + 2);
+    d.e2z = u2f(q2.x); d.id = q2.y;
     return d;
 }
 DEVI float ray_triangle(const Ray &r, const TriData &d) {
@@ -454,7 +456,10 @@ typedef LevelStackT<256> LevelStack;
 // positions per axis (lo, mid, hi), so the reference's per-child (bound - origin) * inverse_direction products and
 // their min/max are computed once per plane pair and shared: every value is produced by the same operation on the same
 // operands as in the reference, only not recomputed.  Returns the existing children that pass as a bitmask over octants.
-DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest) {
+// `inclusive`: a box entered exactly at the closest distance passes too (the exact near-first mode, see Exact): tmin <= closest
+// is tested as tmin < the next float above closest (closest is never negative or NaN here; an infinite tmin fails tmin < tmax).
+DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest, bool inclusive = false) {
+    if (inclusive && closest < __builtin_inff()) closest = closest < 0x1p-126f ? 0x1p-126f : u2f(f2u(closest) + 1u);
     const f3 tl = (lo - r.pos) * r.inv, tm = (mid - r.pos) * r.inv, th = (hi - r.pos) * r.inv;
     // lower half of an axis: box [lo, mid] -> t1 = tl, t2 = tm; upper half: box [mid, hi] -> t1 = tm, t2 = th
     const f3 near0 = F3(fminf(tl.x, tm.x), fminf(tl.y, tm.y), fminf(tl.z, tm.z)), far0 = F3(fmaxf(tl.x, tm.x), fmaxf(tl.y, tm.y), fmaxf(tl.z, tm.z));
@@ -470,16 +475,36 @@ DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t ch
     return oct_pass & child_mask;
 }
 
-struct NodeData { uint32_t tri_start, tri_count, child_mask, first_child; f3 lo, mid, hi; };
-DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
-    const uint4 *rec = reinterpret_cast<const uint4 *>(S.nodes + ni);
-    const uint4 w0 = rec[0];
-    const float4 w1 = reinterpret_cast<const float4 *>(rec)[1], w2 = reinterpret_cast<const float4 *>(rec)[2];
-    const float hiz = reinterpret_cast<const float *>(rec)[12];
+struct NodeData { uint32_t tri_start, tri_count, child_mask, first_child, rank, first_id; f3 lo, mid, hi; };   // first_id: a leaf's first triangle (RtNodeRec::first_id)
+DEVI NodeData unpack_node(const uint4 w0, const float4 w1, const float4 w2, float hiz, uint32_t first_id) {
     NodeData n;
-    n.tri_start = w0.y; n.tri_count = w0.x >> 16; n.child_mask = (w0.x >> 8) & 0xffu; n.first_child = w0.z;
+    n.tri_start = w0.y; n.tri_count = w0.x >> 16; n.child_mask = (w0.x >> 8) & 0xffu; n.first_child = w0.z; n.rank = w0.w; n.first_id = first_id;
     n.lo = F3(w1.x, w1.y, w1.z); n.mid = F3(w1.w, w2.x, w2.y); n.hi = F3(w2.z, w2.w, hiz);
     return n;
+}
+DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
+    const uint4 *rec = reinterpret_cast<const uint4 *>(S.nodes + ni);
+    const uint4 w3 = rec[3];     // hi.z, parent, first_id, pad
+    return unpack_node(rec[0], reinterpret_cast<const float4 *>(rec)[1], reinterpret_cast<const float4 *>(rec)[2], u2f(w3.x), w3.z);
+}
+// The records of the top three levels of the tree (the first RT_TOP_RECORDS records: the root, its block of eight and their
+// blocks), which every ray that enters the octree visits, staged once per workgroup in LDS.
+struct TopLevels { uint4 q[RT_TOP_RECORDS][4]; };
+DEVI void stage_top_levels(TopLevels *top, const RtDeviceScene &S) {      // the caller's next barrier publishes the copy
+    const uint32_t n = min(S.n_nodes, RT_TOP_RECORDS) * 4u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(S.nodes);
+    uint4 *dst = &top->q[0][0];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+template <bool COUNT>
+DEVI NodeData load_node(const RtDeviceScene &S, const TopLevels *top, uint32_t ni, Counters &cn) {
+    if (top && ni < RT_TOP_RECORDS) {
+        if (COUNT) cn.lds_pops++;
+        const uint4 *rec = top->q[ni];
+        const uint4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+        return unpack_node(a, make_float4(u2f(b.x), u2f(b.y), u2f(b.z), u2f(b.w)), make_float4(u2f(c.x), u2f(c.y), u2f(c.z), u2f(c.w)), u2f(d.x), d.z);
+    }
+    return load_node(S, ni);
 }
 
 // The triangle record a leaf carries in place of its box (lo = v1, mid = e1, hi = e2).
@@ -487,7 +512,7 @@ DEVI TriData inline_triangle(const NodeData &n) {
     TriData d;
     d.q0 = make_float4(n.lo.x, n.lo.y, n.lo.z, n.mid.x);
     d.q1 = make_float4(n.mid.y, n.mid.z, n.hi.x, n.hi.y);
-    d.e2z = n.hi.z;
+    d.e2z = n.hi.z; d.id = n.first_id;
     return d;
 }
 
@@ -547,10 +572,58 @@ struct Walk {
     uint32_t key;             // octant permutation of this ray (order_key)
     template <class STACK> DEVI void begin(STACK &st, uint32_t k) { key = k; st.reset_to_root(k); node.child_mask = 0; tri_i = tri_end = 0; }
 };
+
+// Exact near-first traversal (RtLaunch::near_first == 2): the children nearest first, and still the reference shader's
+// result -- the closest distance AND the triangle reference ("slot") it reports -- in three steps per ray.
+//
+// The reference (R) visits a node's passing children in descending octant order, tests `t < closest` strictly, and prunes a
+// child whose box is entered at tmin >= the closest distance known when its parent is visited (frag:456-513).  Its slot is
+// therefore the FIRST one, in its visiting order, among the references with the final distance t* in the nodes it visits.
+//
+//  1. Near-first pass.  Children in the order of the ray's direction, pruning with tmin <= closest (inclusive), accepting
+//     t < closest.  It visits every node entered at tmin <= t* -- which R visits too, as its closest distance stays above t*
+//     until it meets a reference with t* -- so it sees every reference with distance t* in those nodes.  Among the references
+//     of ONE triangle with equal t that it tests it keeps the one whose node has the lowest rank (RtNodeRec::rank: R's visiting
+//     order).  A DIFFERENT triangle at the bit-equal distance sets `tie`.
+//  2. Candidate check.  A reference can also give t* from a node entered BEHIND the hit point (tmin > t*: the triangle sticks
+//     out of that node's box towards the ray origin).  Whether R visits such a node depends on everything R has met before it.
+//     So the result is `uncertain` if the kept reference's own node is entered behind the hit, or if the ray passes through
+//     the box (tmax > 0 && tmin < tmax) of a node holding one of the references of the same triangle that R would meet
+//     earlier -- the positions [dup_first, dup_pos) of the sorted reference array (RtTriRec); such a node, not tested in
+//     step 1, is necessarily one entered behind the hit.
+//  3. Uncertain or tie: the lane runs the reference's own traversal from the start (fallback), whose result is R's by definition.
+//
+// Which of a triangle's references is reported can only be observed through the optional plane rt_target.hit_slot of the
+// primary hit: every reference of a triangle holds the same vertex indices and material, so distance, normal, colour and
+// depth do not depend on it.  Step 2 therefore runs only for segments whose slot is written out (Exact::slot); all others
+// finish after step 1 unless `tie` is set.
+//
+// When step 1 finds no triangle closer than the initial distance, R -- which visits a subset of step 1's nodes -- finds
+// none either.  What is NOT covered: a ray whose float box and triangle tests disagree about a hit exactly on a box face in
+// such a way that R and the near-first pass end with different closest distances; every parity test runs in this mode too.
+struct Exact {
+    uint32_t best_rank;       // rank of the node that holds closest_tri
+    uint32_t best_id;         // the triangle behind closest_tri (RtTriRec::dup_first)
+    uint32_t post_q, post_end;// candidate positions still to be checked (step 2) while post_q < post_end
+    float closest0;           // closest distance before the octree (for the fallback)
+    bool nf, tie;             // near-first pass running (cleared for the fallback); another triangle at the bit-equal distance
+    bool slot;                // the reference's SLOT is wanted (step 2), not only its distance and triangle
+    DEVI void begin(float c0, bool want_slot) { best_rank = 0; best_id = 0; post_q = post_end = 0; closest0 = c0; nf = true; tie = false; slot = want_slot; }
+};
+template <bool EXACT>
+DEVI void accept_hit(float t, uint32_t slot, uint32_t id, uint32_t node_rank, float &closest, uint32_t &closest_tri, bool &tri_hit, Exact &x) {
+    if (t >= 0.0f && t < closest) {
+        closest = t; closest_tri = slot; tri_hit = true;
+        if (EXACT) { x.best_rank = node_rank; x.best_id = id; x.tie = false; }
+    } else if (EXACT && x.nf && tri_hit && t == closest) {
+        if (id != x.best_id) x.tie = true;
+        else if (node_rank < x.best_rank || (node_rank == x.best_rank && slot < closest_tri)) { closest_tri = slot; x.best_rank = node_rank; }
+    }
+}
 // Must be called by all lanes of a wave together; `active` marks the lanes with a live traversal and is cleared when a
-// lane's stack runs empty.
-template <bool COUNT, class STACK>
-DEVI void walk_step(const RtDeviceScene &S, const Ray &r, STACK &st, Walk &w, bool near_first, float &closest, uint32_t &closest_tri, bool &tri_hit, bool &active, Counters &cn) {
+// lane's traversal is complete.  mode: RtLaunch::near_first (0: the reference's order, 1: near first, 2: exact near first).
+template <bool COUNT, bool EXACT, class STACK>
+DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, STACK &st, Walk &w, Exact &x, bool near_first, float &closest, uint32_t &closest_tri, bool &tri_hit, bool &active, Counters &cn) {
     const bool want_tri = active && w.tri_i < w.tri_end;
     const uint32_t n_tri = (uint32_t)__popcll(__ballot(want_tri)), n_pop = (uint32_t)__popcll(__ballot(active && !want_tri));
     if (n_tri != 0 && n_tri >= n_pop) {
@@ -560,29 +633,71 @@ DEVI void walk_step(const RtDeviceScene &S, const Ray &r, STACK &st, Walk &w, bo
             for (uint32_t k = 0; k < TRI_BATCH; k++) td[k] = load_triangle(S.tris + min(w.tri_i + k, w.tri_end - 1u));
 #pragma unroll
             for (uint32_t k = 0; k < TRI_BATCH; k++) {
-                if (w.tri_i + k < w.tri_end) {
-                    const float t = ray_triangle(r, td[k]);
-                    if (t >= 0.0f && t < closest) { closest = t; closest_tri = w.tri_i + k; tri_hit = true; }
-                }
+                if (w.tri_i + k < w.tri_end) accept_hit<EXACT>(ray_triangle(r, td[k]), w.tri_i + k, td[k].id, w.node.rank, closest, closest_tri, tri_hit, x);
             }
             w.tri_i = min(w.tri_i + TRI_BATCH, w.tri_end);
         }
     } else if (active && !want_tri) {
+        if (EXACT && x.post_q < x.post_end) {
+            // step 2, one candidate per step: the box of the node that holds a reference of the hit triangle, derived from its
+            // parent's record.  For the kept reference itself (the last position) the question is whether its node is entered
+            // no later than the hit (tmin <= t*: then R visits it); for an earlier reference, whether the ray passes through
+            // its node at all (then R may have visited it).
+            const uint32_t po = S.dup_parent[x.post_q];
+            const bool self = x.post_q + 1u == x.post_end;
+            bool uncertain = false;
+            if (po != RT_NO_PARENT) {            // (a reference held by the root: always visited, by both traversals)
+                const NodeData pn = load_node<false>(S, top, po & 0x00FFFFFFu, cn);
+                const uint32_t o = po >> 24;
+                const f3 lo = F3((o & 1u) ? pn.mid.x : pn.lo.x, (o & 2u) ? pn.mid.y : pn.lo.y, (o & 4u) ? pn.mid.z : pn.lo.z);
+                const f3 hi = F3((o & 1u) ? pn.hi.x : pn.mid.x, (o & 2u) ? pn.hi.y : pn.mid.y, (o & 4u) ? pn.hi.z : pn.mid.z);
+                const f3 t1 = (lo - r.pos) * r.inv, t2 = (hi - r.pos) * r.inv;
+                const float tmin = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z));
+                const float tmax = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
+                const bool through = tmax > 0.0f && tmin < tmax;
+                uncertain = self ? !(through && tmin <= closest) : through;
+            }
+            if (COUNT) cn.cand_checks++;
+            if (uncertain) {                     // step 3
+                if (COUNT) cn.fallbacks++;
+                x.post_q = x.post_end = 0; x.nf = false; x.tie = false;
+                closest = x.closest0; closest_tri = 0; tri_hit = false;
+                w.begin(st, 0u);
+            } else if (++x.post_q == x.post_end) {
+                x.post_q = x.post_end = 0;
+                active = false;
+            }
+            return;
+        }
+        const bool nf_pass = EXACT && x.nf;
         if (w.node.child_mask != 0) {
-            uint32_t pass = child_pass_octants(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest);
+            uint32_t pass = child_pass_octants(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest, nf_pass);
             if (near_first) pass = permute_octants(pass, w.key);
             if (pass) st.push_level(w.node.first_child, pass);
             w.node.child_mask = 0;
         }
         if (st.empty()) {
+            if (nf_pass && tri_hit) {
+                const bool redo = x.tie;
+                if (!redo && x.slot) {
+                    x.post_q = S.tris[closest_tri].dup_first; x.post_end = S.tris[closest_tri].dup_pos + 1u;   // (at least the kept reference itself)
+                    return;
+                }
+                if (redo) {
+                    if (COUNT) cn.fallbacks++;
+                    x.nf = false; x.tie = false;
+                    closest = x.closest0; closest_tri = 0; tri_hit = false;
+                    w.begin(st, 0u);
+                    return;
+                }
+            }
             active = false;
         } else {
-            w.node = load_node(S, st.pop_node(w.key));
+            w.node = load_node<COUNT>(S, top, st.pop_node(w.key), cn);
             if (COUNT) { cn.pops++; cn.tri_tests += w.node.tri_count; cn.box_tests += __popc(w.node.child_mask); }
             w.tri_i = w.node.tri_start; w.tri_end = w.node.tri_start + w.node.tri_count;
             if (w.node.child_mask == 0 && w.node.tri_count != 0) {   // a leaf's record holds its first triangle
-                const float t = ray_triangle(r, inline_triangle(w.node));
-                if (t >= 0.0f && t < closest) { closest = t; closest_tri = w.tri_i; tri_hit = true; }
+                accept_hit<EXACT>(ray_triangle(r, inline_triangle(w.node)), w.tri_i, w.node.first_id, w.node.rank, closest, closest_tri, tri_hit, x);
                 w.tri_i++;
             }
         }
@@ -969,17 +1084,18 @@ DEVI uint32_t wave_sum(uint32_t v) {
     return v;
 }
 DEVI void flush_counters(unsigned long long *ctr, const Counters &cn) {
-    const uint32_t v[6] = {wave_sum(cn.rays), wave_sum(cn.pops), wave_sum(cn.tri_tests), wave_sum(cn.box_tests), wave_sum(cn.tri_shaded), wave_sum(cn.entered)};
+    const uint32_t v[10] = {wave_sum(cn.rays), wave_sum(cn.pops), wave_sum(cn.tri_tests), wave_sum(cn.box_tests), wave_sum(cn.tri_shaded), wave_sum(cn.entered), wave_sum(cn.sph_tests),
+                            wave_sum(cn.lds_pops), wave_sum(cn.fallbacks), wave_sum(cn.cand_checks)};
     if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) if (v[k]) atomicAdd(&ctr[k], (unsigned long long)v[k]);
+        for (int k = 0; k < 10; k++) if (v[k]) atomicAdd(&ctr[k], (unsigned long long)v[k]);
     }
 }
 
 #ifdef RT_FULL_SPHERE_LOOP   // A/B switch: test all 84 spheres for every ray
-#define SPHERE_LOOP(PRIMARY, lds, ray, closest, closest_i) do { if (PRIMARY) intersect_spheres_primary((lds).tab, (ray).dir, closest, closest_i); else intersect_spheres((lds).tab, ray, closest, closest_i); } while (0)
+#define SPHERE_LOOP(PRIMARY, lds, ray, closest, closest_i, n_tests) do { if (n_tests) *(n_tests) += NUM_SPHERES; if (PRIMARY) intersect_spheres_primary((lds).tab, (ray).dir, closest, closest_i); else intersect_spheres((lds).tab, ray, closest, closest_i); } while (0)
 #else
-#define SPHERE_LOOP(PRIMARY, lds, ray, closest, closest_i) intersect_spheres_culled<PRIMARY>(&(lds), ray, closest, closest_i)
+#define SPHERE_LOOP(PRIMARY, lds, ray, closest, closest_i, n_tests) intersect_spheres_culled<PRIMARY>(&(lds), ray, closest, closest_i, n_tests)
 #endif
 
 // ================================================================================================
@@ -1051,7 +1167,7 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
     p.active = p.active && frame_ok;
     const bool fused_blend = BATCH && groups == 1u;
     f3 out = F3(0.0f, 0.0f, 0.0f);
-    Counters cn = {0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (p.active) {
         float nx, ny;
         pixel_ndc(L, p, nx, ny);
@@ -1074,11 +1190,11 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
             uint32_t closest_i = 0, closest_tri = 0;
             bool tri_hit = false;
             if (COUNT) cn.rays++;
-            SPHERE_LOOP(false, lds_sph, ray, closest, closest_i);
+            SPHERE_LOOP(false, lds_sph, ray, closest, closest_i, COUNT ? &cn.sph_tests : nullptr);
             if (root_box_test(S, ray, closest)) {
                 if (COUNT) cn.entered++;
                 // (a lane per visit here: with a wave's rays this coherent the wave-wide walk_step measured 10 % slower)
-                const bool near_first = L.near_first != 0u;
+                const bool near_first = L.near_first == 1u;   // (the exact near-first mode is built into the wave-wide traversal only: here it runs the reference's order, which gives the same result)
                 const uint32_t key = order_key(ray, near_first);
                 st.reset_to_root(key);
                 while (!st.empty()) visit_node<COUNT>(S, ray, st, key, near_first, closest, closest_tri, tri_hit, cn);
@@ -1235,6 +1351,8 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
     float4 *__restrict__ B = WS.dir_pix[cur];
     const uint32_t lo = blockIdx.x * RANGE;
     const uint32_t count = D0 ? min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u) : WS.live[cur][blockIdx.x];
+    const bool counting = L.counters != nullptr;
+    uint32_t n_sph = 0;
     for (uint32_t off = 0; off < count; off += 256u) {
         const uint32_t slot = lo + off + threadIdx.x;
         bool valid = off + threadIdx.x < count;
@@ -1258,7 +1376,7 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
             WS.color[cur][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
             if (valid) {
                 ray.inv = rcp3(ray.dir);
-                SPHERE_LOOP(true, lds_sph, ray, closest, closest_i);
+                SPHERE_LOOP(true, lds_sph, ray, closest, closest_i, counting ? &n_sph : nullptr);
                 enter = root_box_test(S, ray, closest);
             }
         } else if (valid) {
@@ -1266,7 +1384,7 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
             ray.pos = F3(a.x, a.y, a.z);
             ray.dir = F3(b.x, b.y, b.z);
             ray.inv = rcp3(ray.dir);
-            SPHERE_LOOP(false, lds_sph, ray, closest, closest_i);
+            SPHERE_LOOP(false, lds_sph, ray, closest, closest_i, counting ? &n_sph : nullptr);
             enter = root_box_test(S, ray, closest);
         }
         if (D0 || valid) {
@@ -1282,11 +1400,21 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
             if (enter) WS.qt[lds_base + rank] = slot;
         }
     }
+    if (counting) {
+        const uint32_t v = wave_sum(n_sph);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&L.counters[6], (unsigned long long)v);
+    }
 }
 
-template <int LEVELS, bool COUNT>
+template <int LEVELS, bool COUNT, bool EXACT>
 __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
+    __shared__ TopLevels lds_top;
+    stage_top_levels(&lds_top, S);
+    __syncthreads();
+    Exact x;
+    x.begin(0.0f, false);
+    const bool want_slot = depth == 0u && L.hit_slot != nullptr;   // the primary hit's slot goes to the caller's plane
     LevelStack st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
@@ -1297,7 +1425,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
     const uint32_t qt_count = ctr[QT_COUNT + cur];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    Counters cn = {0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool has = false, exhausted = false;       // exhausted, batch_next, batch_end are wave-uniform
     uint32_t batch_next = 0, batch_end = 0;
     uint32_t slot = 0, closest_tri = 0;
@@ -1330,6 +1458,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
                 closest = WS.t[slot];
                 closest_tri = 0; tri_hit = false;
                 walk.begin(st, order_key(ray, L.near_first != 0u));
+                if (EXACT) x.begin(closest, want_slot);
                 has = true;
                 if (COUNT) cn.entered++;
             }
@@ -1339,7 +1468,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
         }
         if (busy == 0) { if (exhausted) break; else continue; }
         const bool was = has;
-        walk_step<COUNT>(S, ray, st, walk, L.near_first != 0u, closest, closest_tri, tri_hit, has, cn);
+        walk_step<COUNT, EXACT>(S, &lds_top, ray, st, walk, x, L.near_first != 0u, closest, closest_tri, tri_hit, has, cn);
         if (was && !has) {
             WS.t[slot] = closest;
             if (tri_hit) WS.tri[slot] = closest_tri | 0x80000000u;
@@ -1362,7 +1491,7 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
     const uint32_t lo = blockIdx.x * RANGE;
     const uint32_t count = D0 ? min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u) : WS.live[cur][blockIdx.x];
     uint32_t out_count = 0;    // workgroup-uniform: survivors of this range so far
-    Counters cn = {0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t off = 0; off < count; off += 256u) {
         const uint32_t slot = lo + off + threadIdx.x;
         bool valid = off + threadIdx.x < count;
@@ -1455,13 +1584,17 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
 #ifndef PATH_WAVES_PER_SIMD
 #define PATH_WAVES_PER_SIMD 5
 #endif
-template <int LEVELS, bool COUNT>
+template <int LEVELS, bool COUNT, bool EXACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 20 ? PATH_WAVES_PER_SIMD : 3, LEVELS <= 20 ? PATH_WAVES_PER_SIMD : 3))) void path_kernel(RtDeviceScene S, RtLaunch L, uint32_t *pool, uint32_t n_tiles) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
     __shared__ SphereLds lds_sph;
     __shared__ PortalBasis lds_portals[2];
+    __shared__ TopLevels lds_top;
+    stage_top_levels(&lds_top, S);
     stage_spheres(&lds_sph, c_spheres);
     stage_portals(lds_portals, L.u);
+    Exact x;
+    x.begin(0.0f, false);
     LevelStack st;
     st.col = &lds_stack[threadIdx.x];
     st.sp = 0;
@@ -1487,7 +1620,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
     const unsigned long long t_start = wall_clock64();
 #endif
     uint32_t unit = limit > 0 ? next_unit() : 0xFFFFFFFFu, cursor = 0;   // `cursor` pixels of `unit` are handed out
-    Counters cn = {0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool has_path = false, traversing = false, tri_hit = false;
     Walk walk;
     walk.node.tri_start = walk.node.tri_count = walk.node.child_mask = walk.node.first_child = 0;
@@ -1566,10 +1699,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                 closest = __builtin_inff();
                 closest_i = 0; closest_tri = 0; tri_hit = false;
                 if (COUNT) cn.rays++;
-                SPHERE_LOOP(false, lds_sph, ray, closest, closest_i);
+                SPHERE_LOOP(false, lds_sph, ray, closest, closest_i, COUNT ? &cn.sph_tests : nullptr);
                 if (root_box_test(S, ray, closest)) {
                     if (COUNT) cn.entered++;
                     walk.begin(st, order_key(ray, L.near_first != 0u));
+                    if (EXACT) x.begin(closest, seg == 0u && L.hit_slot != nullptr);
                     traversing = true;
                 }
             }
@@ -1581,7 +1715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                 const unsigned long long w = __ballot(!traversing && (has_path || unit < n_units));
                 if ((uint32_t)__popcll(w) >= (unit < n_units ? PATH_REFILL : 1u)) break;
             }
-            walk_step<COUNT>(S, ray, st, walk, L.near_first != 0u, closest, closest_tri, tri_hit, traversing, cn);
+            walk_step<COUNT, EXACT>(S, &lds_top, ray, st, walk, x, L.near_first != 0u, closest, closest_tri, tri_hit, traversing, cn);
         }
     }
 #ifdef PATH_TRACE   // development aid: per-wave start / end wall clock behind the counters
@@ -1596,8 +1730,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
 
 template <int LEVELS>
 void launch_path(const RtDeviceScene &S, const RtLaunch &L, uint32_t *pool, uint32_t n_tiles, hipStream_t st, dim3 grid) {
-    if (L.counters) hipLaunchKernelGGL((path_kernel<LEVELS, true>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
-    else hipLaunchKernelGGL((path_kernel<LEVELS, false>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
+    if (L.near_first == 2u) {
+        if (L.counters) hipLaunchKernelGGL((path_kernel<LEVELS, true, true>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
+        else hipLaunchKernelGGL((path_kernel<LEVELS, false, true>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
+    } else {
+        if (L.counters) hipLaunchKernelGGL((path_kernel<LEVELS, true, false>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
+        else hipLaunchKernelGGL((path_kernel<LEVELS, false, false>), grid, dim3(256), 0, st, S, L, pool, n_tiles);
+    }
 }
 
 template <int LEVELS>
@@ -1616,8 +1755,13 @@ int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st,
 
 template <int LEVELS>
 void launch_traverse(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace &WS, uint32_t d, hipStream_t st, dim3 grid) {
-    if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true>), grid, dim3(256), 0, st, S, L, WS, d);
-    else hipLaunchKernelGGL((traverse_kernel<LEVELS, false>), grid, dim3(256), 0, st, S, L, WS, d);
+    if (L.near_first == 2u) {
+        if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true, true>), grid, dim3(256), 0, st, S, L, WS, d);
+        else hipLaunchKernelGGL((traverse_kernel<LEVELS, false, true>), grid, dim3(256), 0, st, S, L, WS, d);
+    } else {
+        if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true, false>), grid, dim3(256), 0, st, S, L, WS, d);
+        else hipLaunchKernelGGL((traverse_kernel<LEVELS, false, false>), grid, dim3(256), 0, st, S, L, WS, d);
+    }
 }
 
 }  // namespace

@@ -85,6 +85,72 @@ __global__ __launch_bounds__(BLOCK) void write_nodes_kernel(const uint32_t *__re
     recs[j] = r;
 }
 
+// Subtree sizes of one level (children's sizes are final: levels are processed deepest first).  An empty slot has size 0.
+__global__ __launch_bounds__(BLOCK) void subtree_size_kernel(const RtNodeRec *__restrict__ recs, uint32_t first, uint32_t n, uint32_t *__restrict__ size, bool root_level) {
+    const uint32_t j = first + blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= first + n) return;
+    const RtNodeRec &r = recs[j];
+    const uint32_t mask = (r.info >> 8) & 0xFFu;
+    // a slot of a child block that no child occupies is all zero; a real node without triangles and children is too, but a
+    // size of 1 or 0 for it changes no comparison between ranks of nodes that hold triangles
+    uint32_t s = (r.info == 0u && !root_level) ? 0u : 1u;
+    for (uint32_t o = 0; o < 8u; o++) if (mask & (1u << o)) s += size[r.first_child + o];
+    size[j] = s;
+}
+// Ranks of the children of one level's nodes: the reference pops the children of a node in descending octant order, each
+// with its whole subtree (frag:456,489-513).
+__global__ __launch_bounds__(BLOCK) void child_rank_kernel(RtNodeRec *__restrict__ recs, uint32_t first, uint32_t n, const uint32_t *__restrict__ size) {
+    const uint32_t j = first + blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= first + n) return;
+    const uint32_t mask = (recs[j].info >> 8) & 0xFFu, fc = recs[j].first_child;
+    uint32_t run = recs[j].rank + 1u;
+    for (int o = 7; o >= 0; o--) {
+        if (!(mask & (1u << o))) continue;
+        recs[fc + o].rank = run;
+        recs[fc + o].parent = j | ((uint32_t)o << 24);
+        run += size[fc + o];
+    }
+}
+// Which node holds each triangle reference (its rank and parent word); references no node holds keep RT_NO_PARENT.
+__global__ __launch_bounds__(BLOCK) void slot_owner_kernel(const RtNodeRec *__restrict__ recs, uint32_t n_nodes, uint32_t n_ref, uint32_t *__restrict__ slot_rank, uint32_t *__restrict__ slot_parent) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_nodes) return;
+    const uint32_t count = recs[j].info >> 16, start = recs[j].tri_start;
+    if (count == 0u || (recs[j].info == 0u)) return;
+    for (uint32_t k = 0; k < count && start + k < n_ref; k++) { slot_rank[start + k] = recs[j].rank; slot_parent[start + k] = recs[j].parent; }
+}
+__global__ __launch_bounds__(BLOCK) void iota_kernel(uint32_t *__restrict__ v, uint32_t n) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+// Sort keys of the references in their current order `perm`: which = 0: i1 << 32 | i2, which = 1: material << 32 | i0.
+__global__ __launch_bounds__(BLOCK) void ref_key_kernel(const uint4 *__restrict__ refs, const uint32_t *__restrict__ perm, uint32_t n, int which, unsigned long long *__restrict__ key) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint4 t = refs[perm[i]];
+    key[i] = which == 0 ? ((unsigned long long)t.y << 32) | t.z : ((unsigned long long)t.w << 32) | t.x;
+}
+// Position of the first reference of each run of equal triangles, as a running maximum over (position if a run starts there).
+__global__ __launch_bounds__(BLOCK) void run_start_kernel(const uint4 *__restrict__ refs, const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ start) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    bool first = i == 0;
+    if (!first) {
+        const uint4 a = refs[perm[i]], b = refs[perm[i - 1]];
+        first = a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+    }
+    start[i] = first ? i : 0u;
+}
+__global__ __launch_bounds__(BLOCK) void dup_write_kernel(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ start, const uint32_t *__restrict__ slot_parent, uint32_t n,
+                                                          RtTriRec *__restrict__ tris, uint32_t *__restrict__ dup_parent) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = perm[i];
+    tris[slot].dup_first = start[i];
+    tris[slot].dup_pos = i;
+    dup_parent[i] = slot_parent[slot];
+}
+
 __global__ __launch_bounds__(BLOCK) void triangle_records_kernel(const float4 *__restrict__ vertices, const uint4 *__restrict__ refs, uint32_t n_ref, RtTriRec *__restrict__ tris) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_ref) return;
@@ -94,7 +160,7 @@ __global__ __launch_bounds__(BLOCK) void triangle_records_kernel(const float4 *_
     r.v1[0] = a.x; r.v1[1] = a.y; r.v1[2] = a.z;
     r.e1x = b.x - a.x; r.e1y = b.y - a.y; r.e1z = b.z - a.z;                // frag:256-257
     r.e2x = c.x - a.x; r.e2y = c.y - a.y; r.e2z = c.z - a.z;
-    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    r.dup_first = r.dup_pos = i; r.pad = 0;
     tris[i] = r;
 }
 
@@ -107,6 +173,7 @@ __global__ __launch_bounds__(BLOCK) void leaf_triangle_kernel(RtNodeRec *__restr
     nodes[i].lo[0] = r.v1[0]; nodes[i].lo[1] = r.v1[1]; nodes[i].lo[2] = r.v1[2];
     nodes[i].mid[0] = r.e1x; nodes[i].mid[1] = r.e1y; nodes[i].mid[2] = r.e1z;
     nodes[i].hi[0] = r.e2x; nodes[i].hi[1] = r.e2y; nodes[i].hi[2] = r.e2z;
+    nodes[i].first_id = r.dup_first;
 }
 
 inline uint32_t grid_for(size_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
@@ -182,15 +249,71 @@ int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref,
         if (e != hipSuccess) { (void)hipFree(all); out->hip_error = (int)e; return RT_ENODEVICE; }
         at += (size_t)chunk_size[l] * sizeof(RtNodeRec);
     }
+    // Rank of every node in the reference traversal's order: subtree sizes deepest level first, then numbering from the root.
+    {
+        Buf size;
+        hipError_t e = size.alloc((size_t)base * sizeof(uint32_t));
+        std::vector<uint32_t> first(chunk_size.size());
+        uint32_t off = 0;
+        for (size_t l = 0; l < chunk_size.size(); l++) { first[l] = off; off += chunk_size[l]; }
+        RtNodeRec *recs = (RtNodeRec *)all;
+        for (size_t l = chunk_size.size(); e == hipSuccess && l-- > 0;) {
+            hipLaunchKernelGGL(subtree_size_kernel, dim3(grid_for(chunk_size[l])), dim3(BLOCK), 0, nullptr, (const RtNodeRec *)recs, first[l], chunk_size[l], (uint32_t *)size.p, l == 0);
+            e = hipGetLastError();
+        }
+        const uint32_t no_parent = RT_NO_PARENT;
+        if (e == hipSuccess) e = hipMemcpy(&recs[0].parent, &no_parent, sizeof no_parent, hipMemcpyHostToDevice);   // (root rank: 0 from the record's initialisation)
+        for (size_t l = 0; e == hipSuccess && l + 1 < chunk_size.size(); l++) {
+            hipLaunchKernelGGL(child_rank_kernel, dim3(grid_for(chunk_size[l])), dim3(BLOCK), 0, nullptr, recs, first[l], chunk_size[l], (const uint32_t *)size.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(all); out->hip_error = (int)e; return RT_ENODEVICE; }
+    }
     out->nodes = (RtNodeRec *)all;
     out->n_nodes = base;
     return RT_OK;
 }
 
-int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris) {
+int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent) {
     if (n_ref) hipLaunchKernelGGL(triangle_records_kernel, dim3(grid_for(n_ref)), dim3(BLOCK), 0, nullptr, (const float4 *)vertices, (const uint4 *)tri_refs, n_ref, tris);
-    if (n_ref && n_nodes) hipLaunchKernelGGL(leaf_triangle_kernel, dim3(grid_for(n_nodes)), dim3(BLOCK), 0, nullptr, nodes, n_nodes, (const RtTriRec *)tris);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess || n_ref == 0) return (int)e;
+    // The references of each triangle, sorted by the rank of the node that holds them (see RtTriRec): a stable radix sort by
+    // rank, then by (i1, i2), then by (material, i0) leaves equal triangles adjacent and in rank order.
+    Buf slot_rank, slot_parent, perm_a, perm_b, key_a, key_b, tmp, start;
+    const size_t n = n_ref;
+    if ((e = slot_rank.alloc(n * 4)) != hipSuccess || (e = slot_parent.alloc(n * 4)) != hipSuccess || (e = perm_a.alloc(n * 4)) != hipSuccess || (e = perm_b.alloc(n * 4)) != hipSuccess ||
+        (e = key_a.alloc(n * 8)) != hipSuccess || (e = key_b.alloc(n * 8)) != hipSuccess || (e = start.alloc(n * 4)) != hipSuccess) return (int)e;
+    if ((e = hipMemset(slot_rank.p, 0xFF, n * 4)) != hipSuccess || (e = hipMemset(slot_parent.p, 0xFF, n * 4)) != hipSuccess) return (int)e;
+    if (n_nodes) hipLaunchKernelGGL(slot_owner_kernel, dim3(grid_for(n_nodes)), dim3(BLOCK), 0, nullptr, (const RtNodeRec *)nodes, n_nodes, n_ref, (uint32_t *)slot_rank.p, (uint32_t *)slot_parent.p);
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, (uint32_t *)perm_a.p, n_ref);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    size_t bytes32 = 0, bytes64 = 0;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes32, (const uint32_t *)slot_rank.p, (uint32_t *)key_a.p, (const uint32_t *)perm_a.p, (uint32_t *)perm_b.p, (int)n)) != hipSuccess) return (int)e;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes64, (const unsigned long long *)key_a.p, (unsigned long long *)key_b.p, (const uint32_t *)perm_a.p, (uint32_t *)perm_b.p, (int)n)) != hipSuccess) return (int)e;
+    if ((e = tmp.alloc(bytes32 > bytes64 ? bytes32 : bytes64)) != hipSuccess) return (int)e;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes32, (const uint32_t *)slot_rank.p, (uint32_t *)key_a.p, (const uint32_t *)perm_a.p, (uint32_t *)perm_b.p, (int)n)) != hipSuccess) return (int)e;
+    uint32_t *cur = (uint32_t *)perm_b.p, *other = (uint32_t *)perm_a.p;
+    for (int which = 0; which < 2; which++) {
+        hipLaunchKernelGGL(ref_key_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, (const uint4 *)tri_refs, (const uint32_t *)cur, n_ref, which, (unsigned long long *)key_a.p);
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        if ((e = hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes64, (const unsigned long long *)key_a.p, (unsigned long long *)key_b.p, (const uint32_t *)cur, other, (int)n)) != hipSuccess) return (int)e;
+        std::swap(cur, other);
+    }
+    hipLaunchKernelGGL(run_start_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, (const uint4 *)tri_refs, (const uint32_t *)cur, n_ref, (uint32_t *)start.p);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    {
+        size_t sb = 0;
+        if ((e = hipcub::DeviceScan::InclusiveScan(nullptr, sb, (const uint32_t *)start.p, (uint32_t *)start.p, hipcub::Max(), (int)n)) != hipSuccess) return (int)e;
+        Buf scan_tmp;
+        if ((e = scan_tmp.alloc(sb)) != hipSuccess) return (int)e;
+        if ((e = hipcub::DeviceScan::InclusiveScan(scan_tmp.p, sb, (const uint32_t *)start.p, (uint32_t *)start.p, hipcub::Max(), (int)n)) != hipSuccess) return (int)e;
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(dup_write_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, (const uint32_t *)cur, (const uint32_t *)start.p, (const uint32_t *)slot_parent.p, n_ref, tris, dup_parent);
+    if (n_nodes) hipLaunchKernelGGL(leaf_triangle_kernel, dim3(grid_for(n_nodes)), dim3(BLOCK), 0, nullptr, nodes, n_nodes, (const RtTriRec *)tris);
+    e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     return (int)e;
 }

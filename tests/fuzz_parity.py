@@ -46,15 +46,21 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--near-first", action="store_true", help="also render with RT_ORDER_NEAR_FIRST and count the pixels whose colour differs from the oracle's (that mode is held to a tolerance, not to bit identity: differences are reported, not failures)")
     ap.add_argument("--ndc-table", action="store_true", help="hand both sides a per-pixel NDC table (the closed form moved by a few units in the last place, as a rasteriser's interpolation does) instead of the closed form")
-    ap.add_argument("--scene", default="bunny", choices=["bunny", "small"], help="small: a cluster of meshes carrying all seven materials on triangles")
+    ap.add_argument("--scene", default="bunny", choices=["bunny", "small", "s100k", "s1m", "deep"],
+                    help="small: a cluster of meshes carrying all seven materials on triangles; s100k / s1m: the seeded synthetic scenes of the benchmark; deep: a 26-level tree")
+    ap.add_argument("--order", default="reference", choices=["reference", "near_first_exact"],
+                    help="child order of the traversal for the bit-exact comparison: the shader's own, or nearest first with the shader's result "
+                         "(every view is then also rendered without the debug planes, where that mode skips resolving the slot)")
     a = ap.parse_args()
     from oracle import oracle
     from raytracer_amd import api, scenes
     rng = np.random.default_rng(a.seed)
-    oc = scenes.default_octree() if a.scene == "bunny" else scenes.small_test_scene()
+    oc = {"bunny": scenes.default_octree, "small": scenes.small_test_scene, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "deep": scenes.deep_test_scene}[a.scene]()
     sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
     osc = oracle.OracleScene(oc.as_dict(), sky)
     sc = api.Scene.from_octree(oc); sc.set_skybox(sky)
+    sc.set_traversal_order(a.order)
+    fallbacks = checks = 0
     bad = 0
     nf_pixels = nf_diff = nf_beyond = nf_slot = 0
     for v in range(a.views):
@@ -75,13 +81,16 @@ def main():
             diffs = {k: int((np.ascontiguousarray(got[k]).view(np.uint32) != np.ascontiguousarray(want[k]).view(np.uint32)).sum()) for k in ("rgba", "depth")}
             diffs.update({k: int((got[k] != want[k]).sum()) for k in ("kind", "slot", "nrays")})
             diffs["t"] = int((got["t"].view(np.uint32)[traced] != want["t"].view(np.uint32)[traced]).sum())
+            if a.order != "reference":
+                bare = sc.render(u, w, h, ndc=ndc, planes=False)
+                diffs.update({k + " without planes": int((np.ascontiguousarray(bare[k]).view(np.uint32) != np.ascontiguousarray(want[k]).view(np.uint32)).sum()) for k in ("rgba", "depth")})
             if any(diffs.values()):
                 bad += 1
                 print(f"MISMATCH view {v} seed {a.seed} {pipe} {w}x{h} limit {int(u[19:20].view(np.uint32)[0])}: {diffs}", flush=True)
         if a.near_first:
             sc.set_pipeline("megakernel"); sc.set_traversal_order("near_first")
             got = sc.render(u, w, h)
-            sc.set_traversal_order("reference")
+            sc.set_traversal_order(a.order)
             err = np.nan_to_num(np.abs(got["rgba"][..., :3].astype(np.float64) - want["rgba"][..., :3]), nan=np.inf).max(-1)
             same_nan = np.isnan(got["rgba"][..., :3]).any(-1) & np.isnan(want["rgba"][..., :3]).any(-1)
             err[same_nan] = 0.0

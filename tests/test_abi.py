@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(api.rt_uniforms) == 280
     assert C.sizeof(api.rt_frame) == 280 + 8 * 4 + 3 * 8
     assert C.sizeof(api.rt_target) == 8 + 6 * 8
-    assert C.sizeof(api.rt_stats) == 48
+    assert C.sizeof(api.rt_stats) == 80
 
 
 def test_argument_validation_without_compute():

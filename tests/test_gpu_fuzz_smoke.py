@@ -11,6 +11,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("module,argv", [
     ("fuzz_parity", ["--views", "40", "--seed", "3", "--near-first"]),
     ("fuzz_parity", ["--views", "30", "--seed", "4", "--scene", "small", "--ndc-table"]),
+    ("fuzz_parity", ["--views", "30", "--seed", "5", "--order", "near_first_exact"]),
+    ("fuzz_parity", ["--views", "20", "--seed", "6", "--scene", "s100k", "--order", "near_first_exact"]),
+    ("fuzz_parity", ["--views", "12", "--seed", "7", "--scene", "deep", "--order", "near_first_exact", "--ndc-table"]),
     ("fuzz_sequences", ["--cases", "25", "--seed", "3"]),
     ("fuzz_octree", ["--cases", "25", "--seed", "3"]),
     ("fuzz_scene_validation", ["--cases", "300", "--seed", "3"]),

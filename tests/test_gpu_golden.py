@@ -20,10 +20,21 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.fixture(scope="module", params=["persistent", "wavefront", "megakernel"])
+# pipeline + child order of the octree traversal: the shader's own, and nearest-first with the shader's result
+# ("exact": built into the wave-wide traversal of the persistent and wavefront pipelines)
+MODES = ["persistent", "wavefront", "megakernel", "persistent+exact", "wavefront+exact"]
+
+
+def set_mode(sc, mode):
+    pipe, _, order = mode.partition("+")
+    sc.set_pipeline(pipe)
+    sc.set_traversal_order("near_first_exact" if order == "exact" else "reference")
+
+
+@pytest.fixture(scope="module", params=MODES)
 def gpu_scene(request, bunny_octree):
     sc = api.Scene.from_octree(bunny_octree)
-    sc.set_pipeline(request.param)
+    set_mode(sc, request.param)
     yield sc
     sc.close()
 
@@ -54,7 +65,7 @@ def test_hip_matches_llvmpipe_view(gpu_scene, path):
 SCENE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "refscene_*.npz")))
 
 
-@pytest.mark.parametrize("pipeline", ["persistent", "wavefront", "megakernel"])
+@pytest.mark.parametrize("pipeline", MODES)
 @pytest.mark.parametrize("path", SCENE_FILES, ids=[os.path.basename(p)[9:-4] for p in SCENE_FILES])
 def test_hip_matches_llvmpipe_on_other_scenes(path, pipeline):
     """Scenes other than the bunny, stored with their arrays: every material on mesh triangles, the reference's quad mesh."""
@@ -62,7 +73,7 @@ def test_hip_matches_llvmpipe_on_other_scenes(path, pipeline):
     w, h = (int(v) for v in z["size"])
     sc = api.Scene.from_dict({k[6:]: z[k] for k in z.files if k.startswith("scene_")})
     sc.set_skybox(z["sky"])
-    sc.set_pipeline(pipeline)
+    set_mode(sc, pipeline)
     try:
         check(sc.render(z["uniforms"], w, h), z)
     finally:

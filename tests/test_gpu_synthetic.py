@@ -20,7 +20,13 @@ from raytracer_amd.params import Uniforms
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-PIPELINES = ["megakernel", "wavefront", "persistent"]
+PIPELINES = ["megakernel", "wavefront", "persistent", "wavefront+exact", "persistent+exact"]   # "+exact": nearest-first child order with the shader's result
+
+
+def set_mode(sc, mode):
+    pipe, _, order = mode.partition("+")
+    sc.set_pipeline(pipe)
+    sc.set_traversal_order("near_first_exact" if order == "exact" else "reference")
 BUILDERS = {"100k": scenes.synthetic_100k, "1m": scenes.synthetic_1m}
 W, H = 3840, 2160
 
@@ -80,9 +86,9 @@ def test_hip_matches_llvmpipe_on_the_synthetic_scenes(synthetic, view):
     w, h = (int(v) for v in z["size"])
     sc.set_skybox(z["sky"])
     for pipe in PIPELINES:
-        sc.set_pipeline(pipe)
+        set_mode(sc, pipe)
         check(sc.render(z["uniforms"], w, h), z)
-    sc.set_pipeline("auto")
+    set_mode(sc, "auto")
 
 
 def test_4k_frames_of_the_synthetic_scenes_match_the_oracle_on_row_bands(synthetic, test_sky):
@@ -94,9 +100,9 @@ def test_4k_frames_of_the_synthetic_scenes_match_the_oracle_on_row_bands(synthet
     u = Uniforms.from_camera(Camera(aspect=W / H), max_recursion_limit=5).pack()
     frames = {}
     for pipe in PIPELINES:
-        sc.set_pipeline(pipe)
+        set_mode(sc, pipe)
         frames[pipe] = sc.render(u, W, H)
-    sc.set_pipeline("auto")
+    set_mode(sc, "auto")
     g = frames["megakernel"]
     for pipe in PIPELINES[1:]:
         for k in ("kind", "slot", "nrays", "t", "depth", "rgba"):
@@ -127,11 +133,11 @@ def test_deep_tree_runs_the_deep_stack_kernels(test_sky):
     sc = api.Scene.from_octree(oc)
     sc.set_skybox(z["sky"])
     for pipe in PIPELINES:
-        sc.set_pipeline(pipe)
+        set_mode(sc, pipe)
         check(sc.render(z["uniforms"], w, h), z)
     # and through a sequence (the batched one-kernel launch has its own deep-stack instantiation)
     import torch
-    sc.set_pipeline("megakernel")
+    set_mode(sc, "megakernel")
     us = [z["uniforms"].copy() for _ in range(4)]
     for k, u in enumerate(us):
         u[20] = k / 60.0
@@ -164,9 +170,10 @@ def test_hip_matches_llvmpipe_at_the_benchmark_frame_sizes(bunny_octree, size):
     sc = api.Scene.from_octree(bunny_octree)
     sc.set_skybox(z["sky"])
     for pipe in PIPELINES:
-        sc.set_pipeline(pipe)
+        set_mode(sc, pipe)
         g = sc.render(z["uniforms"], w, h, ndc=(nx, ny))
         check({k: v[sl] for k, v in g.items()}, z)
+    set_mode(sc, "megakernel")
     # the closed form does not reproduce the band (the unprojection rounds most of the ulp differences away; the pixels
     # whose seed they do reach -- about one in a thousand -- trace different paths)
     g2 = sc.render(z["uniforms"], w, h)

@@ -3,18 +3,26 @@
   <tag>_bench.json          the bench line
   <tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary (per-kernel calls / total / average ns)
   <tag>_pmc.json            mean counter value per kernel dispatch, per kernel
-  hbm_traffic.json          HBM bytes per launch of the dominant kernels, read by bench.py for roofline.traffic
-usage: tools/profile_digest.py <tag>"""
+  pmc_digest.json           per workload ("scene:WxH:limitN:order") and kernel: HBM bytes per launch and the derived figures
+                            bench.py reports (roofline.traffic, roofline.counters); entries of other workloads are kept
+usage: tools/profile_digest.py <tag> [directory under gpurun_out/, default prof]"""
 import collections, csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst, tag = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles"), sys.argv[1]
+src, dst, tag = os.path.join(root, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "prof"), os.path.join(root, "profiles"), sys.argv[1]
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+bench = json.load(open(os.path.join(src, "bench.json")))
+cfg = bench["config"]
+order = "near_first" if cfg["traversal_order"].startswith("near_first") else "reference"
+key = f"{cfg['scene']}:{cfg['width']}x{cfg['height']}:limit{cfg['max_recursion_limit']}:{order}"
+def short(name):
+    return name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+kernel_ns = {}
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
-def short(name):
-    return name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+    for row in csv.DictReader(open(stats[0])):
+        kernel_ns[short(row["Name"])] = (float(row["AverageNs"]), int(row["Calls"]))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
@@ -22,17 +30,41 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
 pmc = {k: {c: {"mean": sum(v) / len(v), "dispatches": len(v)} for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())
        if any(t in k for t in ("render_kernel", "render_batch_kernel", "blend_batch_kernel", "spheres_kernel", "traverse_kernel", "shade_kernel", "path_kernel"))}
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
-traffic = {}
+N_SIMD = 256 * 4          # MI355X: 256 compute units of four SIMDs
+digest = {}
 for k, cs in pmc.items():
-    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        base = k.split("<")[0]
-        if ", true" in k and any(o.split("<")[0] == base and ", true" not in o for o in pmc):
-            continue   # the variant with work counters on is not the one that is timed
-        # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so it is doubled
-        # (exact for wide coalesced reads, an upper bound for this kernel's scattered 64-byte gathers)
-        traffic[base] = {"hbm_bytes_per_launch": int((2.0 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024),
-                         "fetch_size_kib_raw": cs["FETCH_SIZE"]["mean"], "write_size_kib_raw": cs["WRITE_SIZE"]["mean"], "source": tag + "_pmc.json"}
-json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1))
-for k, cs in pmc.items():
-    print(k, {c: round(v["mean"], 1) for c, v in cs.items()})
+    if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
+        continue
+    base = k.split("<")[0]
+    if ", true" in k and any(o.split("<")[0] == base and ", true" not in o for o in pmc):
+        continue   # the variant with work counters on is not the one that is timed
+    m = {c: v["mean"] for c, v in cs.items()}
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so it is
+    # doubled (exact for wide coalesced reads, an upper bound for this kernel's scattered 64-byte gathers)
+    d = {"hbm_bytes_per_launch": int((2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024), "fetch_size_kib_raw": m["FETCH_SIZE"], "write_size_kib_raw": m["WRITE_SIZE"],
+         "kernel": k, "source": tag + "_pmc.json"}
+    if k in kernel_ns:
+        d["kernel_ms"], d["kernel_calls"] = kernel_ns[k][0] * 1e-6, kernel_ns[k][1]
+        d["hbm_gbs"] = d["hbm_bytes_per_launch"] / (d["kernel_ms"] * 1e-3) / 1e9
+    if "GRBM_GUI_ACTIVE" in m:
+        cyc = m["GRBM_GUI_ACTIVE"] / 8.0     # summed over the 8 XCDs
+        d["cycles"] = cyc
+        if "kernel_ms" in d:
+            d["clock_ghz"] = cyc / (d["kernel_ms"] * 1e6)
+        if "SQ_INSTS_VALU" in m:
+            d["valu_issue_frac"] = m["SQ_INSTS_VALU"] / (cyc * N_SIMD * 0.5)      # a wave64 VALU instruction occupies its SIMD for 2 cycles
+        if "SQ_WAVE_CYCLES" in m:
+            d["occupancy_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4.0 / (cyc * N_SIMD)   # SQ_WAVE_CYCLES counts quad-cycles
+    if m.get("SQ_ACTIVE_INST_VALU"):
+        d["lanes_active_of_64"] = m["SQ_THREAD_CYCLES_VALU"] / m["SQ_ACTIVE_INST_VALU"]
+    if m.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in m:
+        d["wait_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    if m.get("TCC_HIT_sum") is not None and (m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)) > 0:
+        d["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+    digest[base] = d
+path = os.path.join(dst, "pmc_digest.json")
+allw = json.load(open(path)) if os.path.exists(path) else {}
+allw[key] = digest
+json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
+print(key)
+print(json.dumps(digest, indent=1))

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--pipelines", default="wavefront,megakernel")
     ap.add_argument("--subframes", default="4", help="comma list of sub-frame counts")
-    ap.add_argument("--order", default="reference", choices=["reference", "near_first"])
+    ap.add_argument("--order", default="reference", choices=["reference", "near_first", "near_first_exact"])
     ap.add_argument("--host", action="store_true", help="host-memory target: every frame is staged over PCIe")
     ap.add_argument("--sequence", action="store_true", help="issue the timed frames as one rt_render_sequence call")
     a = ap.parse_args()
