@@ -15,7 +15,9 @@ App::Render does (time advances by 1/60 s per frame).  One step = one frame.  Me
 FindIntersection call (path segment); rays are COUNTED by replaying the timed frames with the library's work counters on.
 
 The same JSON line carries, under "north_star", BASELINE.json configs[3] measured the same way right after the headline
-workload: the seeded 1.28 M-triangle scene (depth-18 octree) at 3840x2160, max_recursion_limit = 5, on the same N GPUs.
+workload: the seeded 1.28 M-triangle scene (depth-18 octree) at 3840x2160, max_recursion_limit = 5, on the same N GPUs,
+with the octree's children visited nearest first (RT_ORDER_NEAR_FIRST_EXACT: outputs bit-identical to the reference
+shader's), and under "north_star_reference_order" the same in the shader's own child order.
 
 N > 1: the frame is sharded by interleaved 16-row strips over the ranks (strong scaling), the scene is broadcast from
 rank 0 over RCCL, every rank accumulates its own bands, and the accumulated frame is gathered to rank 0 with RCCL after
@@ -127,8 +129,9 @@ def main():
                     help="N > 1: the accumulated frame is gathered to rank 0 after every this many steps and after the last one. "
                          "0 = 16 x N: a step takes about 0.67 ms / N, so the frame is presented about 100 times a second whatever N is "
                          "(a 4K RGBA32F frame is 132.7 MB: gathered after every step it would measure the xGMI links, not the renderer)")
-    ap.add_argument("--traversal", default="reference", choices=["reference", "near_first"],
-                    help="child order of the octree traversal: the shader's own (bit-identical results) or nearest first (faster; colour tolerance only)")
+    ap.add_argument("--traversal", default="reference", choices=["reference", "near_first", "near_first_exact"],
+                    help="child order of the octree traversal: the shader's own; nearest first (faster; colour tolerance only); nearest first with the "
+                         "shader's result (bit-identical outputs: see RT_ORDER_NEAR_FIRST_EXACT in include/rt_hotpath.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the second workload (the 1.28 M-triangle scene at limit 5)")
     args = ap.parse_args()
@@ -186,7 +189,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_workload(scene_name: str, limit: int, steps: int, warmup: int, cpu_leg: bool) -> dict:
+    ORDER_TEXT = {"reference": "reference (the shader's own child order; bit-identical to the reference shader)",
+                  "near_first": "near_first (not the reference's order: colour tolerance only)",
+                  "near_first_exact": "near_first_exact (children nearest first, results bit-identical to the reference shader: the hit's triangle, distance, colour and depth; "
+                                      "the reference's triangle SLOT is resolved only when the hit_slot plane is requested)"}
+
+    def run_workload(scene_name: str, limit: int, steps: int, warmup: int, cpu_leg: bool, traversal: str) -> dict:
         """Builds the scene (rank 0, device octree builder; broadcast over RCCL), warms up, times `steps` frames between
         barriers, counts their work in an untimed replay, and returns the fields of the report for this workload."""
         t_build = time.time()
@@ -201,7 +209,7 @@ def main():
         sc = api.Scene.from_dict(scene_arrays, device=local_rank)
         sc.set_skybox(sky)
         sc.set_pipeline(args.pipeline)
-        sc.set_traversal_order(args.traversal)
+        sc.set_traversal_order(traversal)
         if args.subframes:
             sc.set_subframes(args.subframes)
         t_build = time.time() - t_build
@@ -303,7 +311,7 @@ def main():
             "scene_build_s": round(t_build, 3),
         }
         rep["config"]["pipeline"] = pipeline + (" (selected by the library: measured ms/frame %s)" % {k: (round(v, 3) if v is not None else None) for k, v in pipeline_ms.items()} if args.pipeline == "auto" else "")
-        rep["config"]["traversal_order"] = args.traversal + (" (bit-identical to the reference shader)" if args.traversal == "reference" else " (not the reference's order: colour tolerance only)")
+        rep["config"]["traversal_order"] = ORDER_TEXT[traversal]
         rep["config"]["issue"] = ("rt_render_sequence over the K steps" if world == 1 else f"rt_render_sequence per {present_every} steps") if sequence else "one rt_render per step"
         # ---- roofline of the dominant kernel, this rank's launches ----------------------------------------------
         kernel = {"wavefront": "traverse_kernel", "megakernel": "render_kernel", "persistent": "path_kernel"}[pipeline]
@@ -314,7 +322,7 @@ def main():
         total_bytes = traversal_bytes(local_tot) if pipeline == "wavefront" else frame_bytes(local_tot, px_local * steps, blended=True)
         abytes = total_bytes / max(k_launches, 1)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        pmc = counter_digest(workload_key(scene_name, W, H, limit, args.traversal), kernel) if world == 1 else None
+        pmc = counter_digest(workload_key(scene_name, W, H, limit, traversal), kernel) if world == 1 else None
         # What limits the kernel is read from the counters of this workload when they have been collected; the achieved
         # figure itself is the prescribed one: algorithmic bytes of the reference's data layout over the measured duration.
         bound = "hbm"
@@ -367,7 +375,7 @@ def main():
         del color
         return rep
 
-    main_rep = run_workload(args.scene, args.max_recursion_limit, args.steps, args.warmup, cpu_leg=not args.no_cpu_baseline)
+    main_rep = run_workload(args.scene, args.max_recursion_limit, args.steps, args.warmup, cpu_leg=not args.no_cpu_baseline, traversal=args.traversal)
     out = {
         "metric": "Mrays/s (primary+secondary) & frame ms at 4K, 1/2/4/8 MI355X vs llvmpipe CPU",
         "value": main_rep.pop("value"), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -379,11 +387,13 @@ def main():
     main_rep.pop("steps"); main_rep.pop("warmup")
     out.update(main_rep)
     if not args.no_north_star and (args.scene, args.max_recursion_limit) != ("synthetic_1m", 5):
-        ns = run_workload("synthetic_1m", 5, max(4, min(args.steps, 12)), min(args.warmup, 2), cpu_leg=False)
-        ns["unit"] = "Mrays/s"
-        ns["n_gpus"] = world
-        ns["what"] = "BASELINE.json configs[3] (>= 1 M primitives, deep octree, incoherent secondary rays, 4K, tile-split over the same ranks), measured like the headline workload"
-        out["north_star"] = ns
+        for name, order in (("north_star", "near_first_exact"), ("north_star_reference_order", "reference")):
+            ns = run_workload("synthetic_1m", 5, max(4, min(args.steps, 12)), min(args.warmup, 2), cpu_leg=False, traversal=order)
+            ns["unit"] = "Mrays/s"
+            ns["n_gpus"] = world
+            ns["what"] = ("BASELINE.json configs[3] (>= 1 M primitives, deep octree, incoherent secondary rays, 4K, tile-split over the same ranks), measured like the "
+                          "headline workload; " + ("octree children visited nearest first with the reference shader's results" if order != "reference" else "the same in the shader's own child order"))
+            out[name] = ns
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -71,7 +71,7 @@ int noalloc_setup(int dev) {
 struct rt_scene {
     int device = 0;
     RtDeviceScene d{};
-    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_dup = nullptr, *d_sky = nullptr;
+    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_dup = nullptr, *d_risky = nullptr, *d_sky = nullptr;
     unsigned long long *d_counters = nullptr;
     bool counting = false;
     // staging for host-memory targets
@@ -240,6 +240,14 @@ int rt_internal_math_check(int op, unsigned long long mismatches[2]) {
     return RT_OK;
 }
 
+// Verification hook (not part of the ABI): node records (empty slots of child blocks included), deepest level, triangle references,
+// triangles lying in a face plane of their node.
+int rt_internal_scene_info(rt_scene *s, uint32_t out[4]) {
+    if (!s || !out) return fail(RT_EINVAL, "null argument");
+    out[0] = s->d.n_nodes; out[1] = s->d.max_depth; out[2] = s->d.n_ref; out[3] = s->d.n_risky;
+    return RT_OK;
+}
+
 // Development hook (not part of the ABI): copies the tile-counter block of sub-frame 0 to the host.
 int rt_internal_read_pool(rt_scene *s, void *out, size_t bytes) {
     if (!s || !s->sub[0].pool || bytes > rt_pool_bytes()) return fail(RT_EINVAL, "no pool");
@@ -328,7 +336,8 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     if (n_ref) {
         hipError_t e = hipMalloc(&s->d_tris, n_ref * sizeof(RtTriRec));
         if (e == hipSuccess) e = hipMalloc(&s->d_dup, n_ref * sizeof(uint32_t));
-        if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes, (RtTriRec *)s->d_tris, (uint32_t *)s->d_dup);
+        if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes, (RtTriRec *)s->d_tris, (uint32_t *)s->d_dup,
+                                                                    (RtTriRec **)&s->d_risky, &s->d.n_risky);
         if (e != hipSuccess) { rt_scene_destroy(s); return fail(e == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "triangle records: %s", hipGetErrorString(e)); }
     }
     if (hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_counters, 0, 128) != hipSuccess) {
@@ -336,7 +345,7 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
         return fail(RT_ENOMEM, "cannot allocate counters");
     }
     s->d.vertices = (const float *)s->d_vertices; s->d.normals = (const float *)s->d_normals; s->d.tri_refs = (const uint32_t *)s->d_refs;
-    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.sky = nullptr;
+    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.risky_tris = (const RtTriRec *)s->d_risky; s->d.sky = nullptr;
     s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = nb.n_nodes;
     s->d.sky_w = s->d.sky_h = 0;
     for (int k = 0; k < 3; k++) { s->d.bounds_min[k] = bounds_min[k]; s->d.bounds_max[k] = bounds_max[k]; }
@@ -570,7 +579,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
     L.n_local_rows = band_rows_of(f);   // rows owned by this part: whole strips, the last one clipped by the kernel
     L.compact_rows = f->compact_rows;
-    L.near_first = (uint32_t)s->order;
+    L.near_first = (s->order == RT_ORDER_NEAR_FIRST_EXACT && s->d.n_risky == RT_RISKY_TOO_MANY) ? 0u : (uint32_t)s->order;   // (see RtDeviceScene::risky_tris)
     L.n_cu = (uint32_t)s->n_cu;
     L.counters = s->counting ? s->d_counters : nullptr;
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 128, st));
@@ -858,7 +867,7 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
 int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     DeviceGuard guard(s->device);
-    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_dup, s->d_sky, s->d_counters};
+    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_dup, s->d_risky, s->d_sky, s->d_counters};
     for (void *q : p) if (q) (void)hipFree(q);
     free_staging(s);
     for (rt_scene::Sub &sb : s->sub) {

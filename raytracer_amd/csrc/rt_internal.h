@@ -11,7 +11,8 @@
 // (max+min)/2 is computed ahead of time with the same two IEEE operations).  Records are laid out breadth-first; a node
 // with children owns a block of eight consecutive records, the child in octant o being record first_child + o (the
 // slots of children that do not exist are never read), so a visit turns "octant passes the slab test" into a record
-// index without counting mask bits.  A leaf (no children, so no child boxes to derive) carries the record of its first
+// index without counting mask bits.  Every block starts at a multiple of eight (the root is record 0 of a block of its
+// own), so a traversal stack entry names a block by first_child / 8.  A leaf (no children, so no child boxes to derive) carries the record of its first
 // triangle in the box fields: lo = v1, mid = e1, hi = e2.  Built from the reference node words (Octree.cpp:44-75) by
 // rt_scene_create.
 struct alignas(64) RtNodeRec {
@@ -23,14 +24,16 @@ struct alignas(64) RtNodeRec {
     float lo[3];
     float mid[3];
     float hi[3];
-    uint32_t parent;      // record index of the parent | octant << 24 (RT_NO_PARENT for the root)
+    uint32_t parent;      // record index of the parent | octant << 27 (RT_NO_PARENT for the root)
     uint32_t first_id;    // a leaf: RtTriRec::dup_first of its first triangle (the one carried in the box fields)
     uint32_t pad;
 };
 #define RT_NO_PARENT 0xFFFFFFFFu
+#define RT_PARENT_INDEX(word) ((word) & 0x07FFFFFFu)
+#define RT_PARENT_OCTANT(word) (((word) >> 27) & 7u)
 static_assert(sizeof(RtNodeRec) == 64, "node record must be one 64-byte line");
 #define RT_MAX_SUBFRAMES 8
-#define RT_MAX_NODE_RECORDS (1u << 24)   // a traversal stack entry packs a record index into 24 bits
+#define RT_MAX_NODE_RECORDS (1u << 27)   // a traversal stack entry packs the index of a block of eight records into 24 bits
 
 // One triangle reference prepared for Moeller-Trumbore: first vertex and the two edges, computed once per scene with
 // the same IEEE subtractions the shader performs per test (frag:256-257), so a test needs three 16-byte loads
@@ -54,6 +57,13 @@ struct RtDeviceScene {
     const RtNodeRec *nodes;    // [n_nodes]
     const RtTriRec *tris;      // [n_ref]
     const uint32_t *dup_parent; // [n_ref]: by position in the sorted reference array (see RtTriRec): `parent` word of the node holding that reference
+    // Triangles that lie IN a face plane of a node that references them (all three vertices share a coordinate equal to the
+    // box bound; the triangles on the faces of the root box, whose bounds are the extreme vertices, are such triangles).  The
+    // reference's triangle/box test, in floating point, may or may not list such a triangle in the other nodes whose face it
+    // lies in, so a ray can hit it before entering any node that holds it and what the reference's traversal makes of it depends
+    // on its visiting order.  A ray that hits one of them is traversed in the reference's own order (see Exact in rt_kernels.hip).
+    const RtTriRec *risky_tris; // [n_risky] copies of their records (one per triangle)
+    uint32_t n_risky;           // RT_RISKY_TOO_MANY: more than RT_MAX_RISKY, the exact near-first order is not used for this scene
     const uint8_t *sky;        // [6][sky_h][sky_w][4] or null
     uint32_t n_vert, n_ref, n_nodes;
     int32_t sky_w, sky_h;
@@ -139,10 +149,14 @@ size_t rt_pool_bytes();   // size of the persistent path kernel's tile-counter b
 #define RT_NODE_ERROR_TOO_MANY 101u
 #define RT_NODE_ERROR_RECORD_LIMIT 102u
 struct RtNodeBuild { RtNodeRec *nodes; uint32_t n_nodes, max_depth, error, error_word; int hip_error; };
-#define RT_TOP_RECORDS 73u   // records of the three top levels (1 + 8 + 64): the part of the tree every entering ray visits
+#define RT_MAX_RISKY 32u
+#define RT_RISKY_TOO_MANY 0xFFFFFFFFu
+#define RT_TOP_RECORDS 80u   // records of the three top levels (the root's block of 8, 8 + 64): the part of the tree every entering ray visits
 int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3], RtNodeBuild *out);
 // dup_parent: n_ref words (see RtDeviceScene).
-int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent);
+// risky / n_risky: see RtDeviceScene (*risky is hipMalloc'ed when *n_risky is in 1..RT_MAX_RISKY; the caller frees).
+int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent,
+                           RtTriRec **risky, uint32_t *n_risky);
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
 // pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:

@@ -428,7 +428,8 @@ DEVI float ray_triangle(const Ray &r, const TriData &d) {
 // passing children of a node are visited in descending octant order, each with its whole subtree, before the
 // node's siblings.  That order is reproduced with ONE entry per tree level instead of one per pending node: an entry
 // holds the record index of the node's block of children and the set of passing children still to visit, as a
-// bitmask over octants (entry = first_child | octant_mask << 24; child o is record first_child + o).  The slab tests happen, as
+// bitmask over octants (entry = first_child / 8 | octant_mask << 24: blocks of children start at multiples of eight; child o is
+// record first_child + o).  The slab tests happen, as
 // in the reference, when the parent is visited -- against the closest distance known at that moment -- and are
 // never repeated.  The stack is a column of LDS: entry k of thread t lives at lds[k * threads + t] (no bank conflicts
 // whatever the lanes' depths), and it can never hold more than one entry per tree level.
@@ -446,9 +447,9 @@ struct LevelStackT {
         const uint32_t rest = mask & ~(1u << r);
         if (rest) col[(sp - 1) * STRIDE] = (e & 0x00FFFFFFu) | (rest << 24);
         else sp--;
-        return (e & 0x00FFFFFFu) + (r ^ key);
+        return ((e & 0x00FFFFFFu) << 3) + (r ^ key);
     }
-    DEVI void push_level(uint32_t first_child, uint32_t octant_mask) { col[sp * STRIDE] = first_child | (octant_mask << 24); sp++; }
+    DEVI void push_level(uint32_t first_child, uint32_t octant_mask) { col[sp * STRIDE] = (first_child >> 3) | (octant_mask << 24); sp++; }
 };
 typedef LevelStackT<256> LevelStack;
 
@@ -487,8 +488,8 @@ DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
     const uint4 w3 = rec[3];     // hi.z, parent, first_id, pad
     return unpack_node(rec[0], reinterpret_cast<const float4 *>(rec)[1], reinterpret_cast<const float4 *>(rec)[2], u2f(w3.x), w3.z);
 }
-// The records of the top three levels of the tree (the first RT_TOP_RECORDS records: the root, its block of eight and their
-// blocks), which every ray that enters the octree visits, staged once per workgroup in LDS.
+// The records of the top three levels of the tree (the first RT_TOP_RECORDS records: the root's block, its children's block and
+// their blocks), which every ray that enters the octree visits, staged once per workgroup in LDS.
 struct TopLevels { uint4 q[RT_TOP_RECORDS][4]; };
 DEVI void stage_top_levels(TopLevels *top, const RtDeviceScene &S) {      // the caller's next barrier publishes the copy
     const uint32_t n = min(S.n_nodes, RT_TOP_RECORDS) * 4u;
@@ -598,6 +599,13 @@ struct Walk {
 // depth do not depend on it.  Step 2 therefore runs only for segments whose slot is written out (Exact::slot); all others
 // finish after step 1 unless `tie` is set.
 //
+// Step 1 relies on every triangle being referenced by the leaf that contains the hit point.  That does not hold for a triangle
+// lying exactly IN a face plane of the boxes around it (RtDeviceScene::risky_tris: e.g. the triangles on the faces of the root box,
+// whose bounds are the extreme vertices): in floating point the reference's triangle/box test lists it in some of those boxes
+// only, a ray can hit it before entering any node that holds it, and whether the reference finds that hit depends on its
+// visiting order.  A ray that hits one of these (few) triangles is therefore traversed in the reference's order from the start
+// (hits_risky); a scene with more than RT_MAX_RISKY of them does not use this mode at all.
+//
 // When step 1 finds no triangle closer than the initial distance, R -- which visits a subset of step 1's nodes -- finds
 // none either.  What is NOT covered: a ray whose float box and triangle tests disagree about a hit exactly on a box face in
 // such a way that R and the near-first pass end with different closest distances; every parity test runs in this mode too.
@@ -610,6 +618,11 @@ struct Exact {
     bool slot;                // the reference's SLOT is wanted (step 2), not only its distance and triangle
     DEVI void begin(float c0, bool want_slot) { best_rank = 0; best_id = 0; post_q = post_end = 0; closest0 = c0; nf = true; tie = false; slot = want_slot; }
 };
+DEVI bool hits_risky(const RtDeviceScene &S, const Ray &r) {
+    bool hit = false;
+    for (uint32_t k = 0; k < S.n_risky; k++) hit = hit || ray_triangle(r, load_triangle(S.risky_tris + k)) >= 0.0f;
+    return hit;
+}
 template <bool EXACT>
 DEVI void accept_hit(float t, uint32_t slot, uint32_t id, uint32_t node_rank, float &closest, uint32_t &closest_tri, bool &tri_hit, Exact &x) {
     if (t >= 0.0f && t < closest) {
@@ -647,8 +660,8 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
             const bool self = x.post_q + 1u == x.post_end;
             bool uncertain = false;
             if (po != RT_NO_PARENT) {            // (a reference held by the root: always visited, by both traversals)
-                const NodeData pn = load_node<false>(S, top, po & 0x00FFFFFFu, cn);
-                const uint32_t o = po >> 24;
+                const NodeData pn = load_node<false>(S, top, RT_PARENT_INDEX(po), cn);
+                const uint32_t o = RT_PARENT_OCTANT(po);
                 const f3 lo = F3((o & 1u) ? pn.mid.x : pn.lo.x, (o & 2u) ? pn.mid.y : pn.lo.y, (o & 4u) ? pn.mid.z : pn.lo.z);
                 const f3 hi = F3((o & 1u) ? pn.hi.x : pn.mid.x, (o & 2u) ? pn.hi.y : pn.mid.y, (o & 4u) ? pn.hi.z : pn.mid.z);
                 const f3 t1 = (lo - r.pos) * r.inv, t2 = (hi - r.pos) * r.inv;
@@ -1458,7 +1471,10 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
                 closest = WS.t[slot];
                 closest_tri = 0; tri_hit = false;
                 walk.begin(st, order_key(ray, L.near_first != 0u));
-                if (EXACT) x.begin(closest, want_slot);
+                if (EXACT) {
+                    x.begin(closest, want_slot);
+                    if (hits_risky(S, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
+                }
                 has = true;
                 if (COUNT) cn.entered++;
             }
@@ -1703,7 +1719,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                 if (root_box_test(S, ray, closest)) {
                     if (COUNT) cn.entered++;
                     walk.begin(st, order_key(ray, L.near_first != 0u));
-                    if (EXACT) x.begin(closest, seg == 0u && L.hit_slot != nullptr);
+                    if (EXACT) {
+                        x.begin(closest, seg == 0u && L.hit_slot != nullptr);
+                        if (hits_risky(S, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
+                    }
                     traversing = true;
                 }
             }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void subtree_size_kernel(const RtNodeRec *__
     const uint32_t mask = (r.info >> 8) & 0xFFu;
     // a slot of a child block that no child occupies is all zero; a real node without triangles and children is too, but a
     // size of 1 or 0 for it changes no comparison between ranks of nodes that hold triangles
-    uint32_t s = (r.info == 0u && !root_level) ? 0u : 1u;
+    uint32_t s = (r.info == 0u && !(root_level && j == 0u)) ? 0u : 1u;
     for (uint32_t o = 0; o < 8u; o++) if (mask & (1u << o)) s += size[r.first_child + o];
     size[j] = s;
 }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void child_rank_kernel(RtNodeRec *__restrict
     for (int o = 7; o >= 0; o--) {
         if (!(mask & (1u << o))) continue;
         recs[fc + o].rank = run;
-        recs[fc + o].parent = j | ((uint32_t)o << 24);
+        recs[fc + o].parent = j | ((uint32_t)o << 27);
         run += size[fc + o];
     }
 }
@@ -118,6 +118,27 @@ __global__ __launch_bounds__(BLOCK) void slot_owner_kernel(const RtNodeRec *__re
     const uint32_t count = recs[j].info >> 16, start = recs[j].tri_start;
     if (count == 0u || (recs[j].info == 0u)) return;
     for (uint32_t k = 0; k < count && start + k < n_ref; k++) { slot_rank[start + k] = recs[j].rank; slot_parent[start + k] = recs[j].parent; }
+}
+// Lists the references of triangles that lie in a face plane of the node holding them (see RtDeviceScene::risky_tris): list[0] counts,
+// list[1 + k] are slots (as many as fit `cap`).  Runs while the leaves' box fields still hold their boxes.
+__global__ __launch_bounds__(BLOCK) void risky_kernel(const RtNodeRec *__restrict__ recs, uint32_t n_nodes, uint32_t n_ref, const uint4 *__restrict__ refs, const float4 *__restrict__ vertices,
+                                                      uint32_t *__restrict__ list, uint32_t cap) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_nodes) return;
+    const uint32_t count = recs[j].info >> 16, start = recs[j].tri_start;
+    if (recs[j].info == 0u || count == 0u) return;
+    for (uint32_t k = 0; k < count && start + k < n_ref; k++) {
+        const uint4 t = refs[start + k];
+        const float4 a = vertices[t.x], b = vertices[t.y], c = vertices[t.z];
+        const float va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z}, vc[3] = {c.x, c.y, c.z};
+        bool risky = false;
+        for (int ax = 0; ax < 3; ax++)
+            if (va[ax] == vb[ax] && vb[ax] == vc[ax] && (va[ax] == recs[j].lo[ax] || va[ax] == recs[j].hi[ax])) risky = true;
+        if (risky) {
+            const uint32_t at = atomicAdd(&list[0], 1u);
+            if (at < cap) list[1u + at] = start + k;
+        }
+    }
 }
 __global__ __launch_bounds__(BLOCK) void iota_kernel(uint32_t *__restrict__ v, uint32_t n) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -201,12 +222,14 @@ int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref,
     std::vector<uint32_t> chunk_size;
     REC_TRY(error.alloc(8));
     REC_TRY(hipMemset(error.p, 0, 8));
-    Entry root;
-    root.word = 0u;
-    for (int k = 0; k < 3; k++) { root.lo[k] = lo0[k]; root.hi[k] = hi0[k]; }
-    REC_TRY(level.alloc(sizeof(Entry)));
-    REC_TRY(hipMemcpy(level.p, &root, sizeof root, hipMemcpyHostToDevice));
-    uint32_t n = 1, base = 0, depth = 0;
+    // level 0 is a block of eight like every other: the root and seven empty slots, so that all blocks start at multiples of 8
+    Entry root[8];
+    for (Entry &e : root) { e.word = HOLE; for (int k = 0; k < 3; k++) { e.lo[k] = 0.0f; e.hi[k] = 0.0f; } }
+    root[0].word = 0u;
+    for (int k = 0; k < 3; k++) { root[0].lo[k] = lo0[k]; root[0].hi[k] = hi0[k]; }
+    REC_TRY(level.alloc(sizeof root));
+    REC_TRY(hipMemcpy(level.p, root, sizeof root, hipMemcpyHostToDevice));
+    uint32_t n = 8, base = 0, depth = 0;
     unsigned long long real_nodes = 1;   // a tree cannot hold more nodes than words: more means shared or cyclic children
     for (;; depth++) {
         REC_TRY(tally.alloc(((size_t)n + 1) * sizeof(Tally)));
@@ -275,7 +298,9 @@ int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref,
     return RT_OK;
 }
 
-int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent) {
+int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent,
+                           RtTriRec **risky, uint32_t *n_risky) {
+    *risky = nullptr; *n_risky = 0;
     if (n_ref) hipLaunchKernelGGL(triangle_records_kernel, dim3(grid_for(n_ref)), dim3(BLOCK), 0, nullptr, (const float4 *)vertices, (const uint4 *)tri_refs, n_ref, tris);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_ref == 0) return (int)e;
@@ -312,6 +337,31 @@ int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint
         if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(dup_write_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, nullptr, (const uint32_t *)cur, (const uint32_t *)start.p, (const uint32_t *)slot_parent.p, n_ref, tris, dup_parent);
+    // triangles in a face plane of their node: the distinct ones (by RtTriRec::dup_first), if they are few
+    if (n_nodes) {
+        constexpr uint32_t CAP = 4096;
+        Buf list;
+        if ((e = list.alloc((CAP + 1) * 4)) != hipSuccess || (e = hipMemset(list.p, 0, 4)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(risky_kernel, dim3(grid_for(n_nodes)), dim3(BLOCK), 0, nullptr, (const RtNodeRec *)nodes, n_nodes, n_ref, (const uint4 *)tri_refs, (const float4 *)vertices, (uint32_t *)list.p, CAP);
+        std::vector<uint32_t> h(CAP + 1);
+        if ((e = hipMemcpy(h.data(), list.p, (CAP + 1) * 4, hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+        if (h[0] > CAP) *n_risky = RT_RISKY_TOO_MANY;
+        else if (h[0]) {
+            std::vector<RtTriRec> recs;
+            for (uint32_t k = 0; k < h[0] && *n_risky != RT_RISKY_TOO_MANY; k++) {
+                RtTriRec r;
+                if ((e = hipMemcpy(&r, tris + h[1 + k], sizeof r, hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+                bool seen = false;
+                for (const RtTriRec &q : recs) seen = seen || q.dup_first == r.dup_first;
+                if (!seen) { if (recs.size() == RT_MAX_RISKY) *n_risky = RT_RISKY_TOO_MANY; else recs.push_back(r); }
+            }
+            if (*n_risky != RT_RISKY_TOO_MANY) {
+                if ((e = hipMalloc((void **)risky, recs.size() * sizeof(RtTriRec))) != hipSuccess) return (int)e;
+                if ((e = hipMemcpy(*risky, recs.data(), recs.size() * sizeof(RtTriRec), hipMemcpyHostToDevice)) != hipSuccess) return (int)e;
+                *n_risky = (uint32_t)recs.size();
+            }
+        }
+    }
     if (n_nodes) hipLaunchKernelGGL(leaf_triangle_kernel, dim3(grid_for(n_nodes)), dim3(BLOCK), 0, nullptr, nodes, n_nodes, (const RtTriRec *)tris);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -180,3 +180,29 @@ def test_hip_matches_llvmpipe_at_the_benchmark_frame_sizes(bunny_octree, size):
     n_diff = int((bits(g2["rgba"][sl][..., :3]) != bits(z["rgb"])).any(-1).sum())
     assert n_diff > 0
     sc.close()
+
+
+def test_scene_beyond_a_24_bit_record_index(test_sky):
+    """5.1 M triangles (4 000 icospheres of 1 280, depth-18 octree): more than 2^24 node records, which a traversal stack entry
+    addresses as blocks of eight (24 bits of block index: 2^27 records).  All pipelines against the oracle, and the near-first
+    order with the shader's result."""
+    import ctypes as C
+    from oracle import oracle
+    meshes = scenes.synthetic_primitives(4000, seed=9, sphere_subdiv=3, extent=3.0, size_range=(0.15, 0.4), materials=(1, 5, 6, 2), perturb=0.01, boxes=False)
+    oc = api.Octree(meshes, 18, 10, 6, 6, device=0)
+    sc = api.Scene.from_octree(oc, device=0)
+    info = (C.c_uint32 * 3)()
+    assert api.lib().rt_internal_scene_info(sc._h, info) == api.RT_OK
+    assert info[0] > (1 << 24) and info[2] == len(oc.m_compressed_triangles) > 30_000_000
+    sc.set_skybox(test_sky)
+    u = Uniforms.from_camera(Camera(aspect=2.0), max_recursion_limit=4).pack()       # (the camera stands among the spheres)
+    o = oracle.OracleScene(oc.as_dict(), test_sky).render(u, 256, 128)
+    assert (o["kind"] == api.HIT_TRIANGLE).mean() > 0.3
+    for pipe in PIPELINES:
+        set_mode(sc, pipe)
+        g = sc.render(u, 256, 128)
+        for k in ("kind", "slot", "nrays"):
+            assert np.array_equal(g[k], o[k]), (pipe, k)
+        for k in ("t", "depth", "rgba"):
+            assert np.array_equal(bits(g[k]), bits(o[k])), (pipe, k)
+    sc.close()

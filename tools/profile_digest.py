@@ -13,7 +13,7 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
 bench = json.load(open(os.path.join(src, "bench.json")))
 cfg = bench["config"]
-order = "near_first" if cfg["traversal_order"].startswith("near_first") else "reference"
+order = cfg["traversal_order"].split(" ")[0]
 key = f"{cfg['scene']}:{cfg['width']}x{cfg['height']}:limit{cfg['max_recursion_limit']}:{order}"
 def short(name):
     return name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
