@@ -36,8 +36,9 @@ for k, cs in pmc.items():
     if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
         continue
     base = k.split("<")[0]
-    if ", true" in k and any(o.split("<")[0] == base and ", true" not in o for o in pmc):
-        continue   # the variant with work counters on is not the one that is timed
+    targs = [a.strip() for a in k.split("<", 1)[1].rstrip(">").split(",")] if "<" in k else []
+    if len(targs) > 1 and targs[1] == "true":
+        continue   # (second template argument: the variant with work counters on, which is not the one that is timed)
     m = {c: v["mean"] for c, v in cs.items()}
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so it is
     # doubled (exact for wide coalesced reads, an upper bound for this kernel's scattered 64-byte gathers)
