@@ -36,6 +36,9 @@ EXPORTED_SYMBOLS = [
     "rt_uniforms_set_camera", "rt_uniforms_set_portals",
     # include/rt_overlay.h
     "rt_depth_to_attachment", "rt_overlay_composite",
+    # include/rt_dist.h (bound in tests/test_gpu_dist_cabi.py)
+    "rt_dist_make_id", "rt_dist_init", "rt_dist_rank", "rt_dist_world_size", "rt_dist_destroy", "rt_dist_scene_create", "rt_dist_skybox_set",
+    "rt_dist_frame_bands", "rt_dist_gather_frame",
 ]
 
 

@@ -216,11 +216,11 @@ int ensure_workspace(rt_scene::Sub *s, size_t slots, size_t ranges) {
     return RT_OK;
 }
 
-int upload(void **dst, const void *src, size_t bytes) {
+int upload(void **dst, const void *src, size_t bytes, bool from_device = false) {
     *dst = nullptr;
     if (bytes == 0) return RT_OK;
     HIP_TRY(hipMalloc(dst, bytes));
-    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(*dst, src, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     return RT_OK;
 }
 
@@ -230,6 +230,7 @@ extern "C" {
 
 const char *rt_last_error(void) { return g_err; }
 int rt_internal_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
+int rt_scene_device(const rt_scene *s) { return s ? s->device : -1; }
 
 // Verification hook (not part of the ABI): the kernels' short 1/x and sqrt sequences against the compiler's correctly rounded
 // ones over all 2^32 inputs; mismatches[0] = count, mismatches[1] = an input that differs.
@@ -275,6 +276,13 @@ int rt_set_device(int device) {
 
 int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
                     const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], rt_scene **out) {
+    return rt_scene_create_from(vertices, normals, n_vert, tri_refs, n_ref, nodes, n_words, bounds_min, bounds_max, 0, out);
+}
+
+// source_is_device: the four arrays are device memory on the current device, already checked by whoever sent them (a rank
+// that received the scene from the root rank, rt_dist.cpp); the bounds are host memory either way.
+int rt_scene_create_from(const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
+                         const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], int source_is_device, rt_scene **out) {
     if (!out) return fail(RT_EINVAL, "out is null");
     *out = nullptr;
     if (!bounds_min || !bounds_max) return fail(RT_EINVAL, "bounds are null");
@@ -286,7 +294,7 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_phase = now();
     double t_check = 0.0, t_flatten = 0.0, t_upload = 0.0;
-    for (size_t i = 0; i < n_ref; i++) {
+    for (size_t i = 0; i < n_ref && !source_is_device; i++) {
         const uint32_t *t = tri_refs + 4 * i;
         if (t[0] >= n_vert || t[1] >= n_vert || t[2] >= n_vert) return fail(RT_ESCENE, "triangle reference %zu indexes vertex >= %zu", i, n_vert);
         if (t[3] >= RT_NUM_MATERIALS) return fail(RT_ESCENE, "triangle reference %zu has material id %u >= %u", i, t[3], RT_NUM_MATERIALS);
@@ -306,8 +314,9 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     if (!guard.ok) { delete s; return fail(RT_ENODEVICE, "cannot select HIP device %d", dev); }
     int rc = RT_OK;
     void *d_words = nullptr;
-    if ((rc = upload(&s->d_vertices, vertices, n_vert * 16)) || (rc = upload(&s->d_normals, normals, n_vert * 16)) ||
-        (rc = upload(&s->d_refs, tri_refs, n_ref * 16)) || (rc = upload(&d_words, nodes, n_words * 4))) {
+    const bool dev_src = source_is_device != 0;
+    if ((rc = upload(&s->d_vertices, vertices, n_vert * 16, dev_src)) || (rc = upload(&s->d_normals, normals, n_vert * 16, dev_src)) ||
+        (rc = upload(&s->d_refs, tri_refs, n_ref * 16, dev_src)) || (rc = upload(&d_words, nodes, n_words * 4, dev_src))) {
         rt_scene_destroy(s);
         return rc;
     }
@@ -361,7 +370,9 @@ int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, 
     return RT_OK;
 }
 
-int rt_skybox_set(rt_scene *s, const uint8_t *const faces[6], int w, int h) {
+int rt_skybox_set(rt_scene *s, const uint8_t *const faces[6], int w, int h) { return rt_skybox_set_from(s, faces, w, h, 0); }
+
+int rt_skybox_set_from(rt_scene *s, const uint8_t *const faces[6], int w, int h, int source_is_device) {
     if (!s || !faces) return fail(RT_EINVAL, "null argument");
     if (w <= 0 || h <= 0 || w > 16384 || h > 16384) return fail(RT_EINVAL, "skybox size %dx%d out of range", w, h);
     for (int f = 0; f < 6; f++) if (!faces[f]) return fail(RT_EINVAL, "face %d is null", f);
@@ -371,7 +382,7 @@ int rt_skybox_set(rt_scene *s, const uint8_t *const faces[6], int w, int h) {
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, fb * 6));
     for (int f = 0; f < 6; f++) {
-        hipError_t e = hipMemcpy((char *)p + fb * f, faces[f], fb, hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpy((char *)p + fb * f, faces[f], fb, source_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(p); return fail(RT_ENODEVICE, "skybox upload: %s", hipGetErrorString(e)); }
     }
     if (s->d_sky) (void)hipFree(s->d_sky);

@@ -163,3 +163,13 @@ size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
 // one-lane-per-pixel kernel; otherwise the per-depth wavefront pipeline.
 int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, uint32_t *pool, void *stream, const char **err, RtProbe *probe = nullptr,
                      const RtBatch *batch = nullptr);   // batch: one-lane-per-pixel pipeline only; launch.u / accum_index / blend are then ignored
+
+// rt_api.cpp, for rt_dist.cpp: scene / skybox creation from arrays that are already in device memory (sent by the root rank), the
+// library's error slot, a scene's device.
+extern "C" {
+int rt_scene_create_from(const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
+                         const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], int source_is_device, rt_scene **out);
+int rt_skybox_set_from(rt_scene *scene, const uint8_t *const faces[6], int w, int h, int source_is_device);
+int rt_internal_set_error(int code, const char *msg);
+int rt_scene_device(const rt_scene *scene);
+}

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     import glob
     headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
-    assert [os.path.basename(h) for h in headers] == ["rt_camera.h", "rt_hotpath.h", "rt_overlay.h"]
+    assert [os.path.basename(h) for h in headers] == ["rt_camera.h", "rt_dist.h", "rt_hotpath.h", "rt_overlay.h"]
     text = "".join(open(h).read() for h in headers)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text)))
