@@ -299,6 +299,13 @@ def sky_size_fixture():
         out = refrun.run_probe(MATH_FRAG, x, 64, 64, sky=sky).reshape(-1, 4)
         rec[f"sky_{size}"] = sky
         rec[f"rgb_{size}"] = out[32 * 64:, :3].copy()
+    # the reference's own face size; the faces are raytracer_amd.scenes.procedural_skybox(900) (seeded: not stored, only their digest)
+    from raytracer_amd import scenes
+    import hashlib
+    sky = scenes.procedural_skybox(900)
+    out = refrun.run_probe(MATH_FRAG, x, 64, 64, sky=sky).reshape(-1, 4)
+    rec["sky_900_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(sky).tobytes()).digest(), np.uint8).copy()
+    rec["rgb_900"] = out[32 * 64:, :3].copy()
     np.savez_compressed(os.path.join(GOLDEN, "ref_sky_sizes.npz"), **rec)
     print("sky sizes", os.path.getsize(os.path.join(GOLDEN, "ref_sky_sizes.npz")))
 

@@ -292,7 +292,7 @@ def test_batched_sequence_of_small_frames(bunny_octree, test_sky):
 @pytest.mark.parametrize("size", [9, 30, 900])
 def test_skybox_face_sizes(bunny_octree, size):
     """The environment lookup scales coordinates by the face size: sizes that are not powers of two, and the reference's
-    own 900 x 900 (the oracle's lookup is pinned to llvmpipe at 9, 30 and 100 by tests/golden/ref_sky_sizes.npz)."""
+    own 900 x 900 (the oracle's lookup is pinned to llvmpipe at 9, 30, 100 and 900 by tests/golden/ref_sky_sizes.npz)."""
     from oracle import oracle
     sky = scenes.procedural_skybox(size) if size == 900 else np.random.default_rng(size).integers(0, 256, size=(6, size, size, 4), dtype=np.uint8)
     sc = api.Scene.from_octree(bunny_octree)
