@@ -1,12 +1,12 @@
-/* rt_overlay.h -- the depth-buffer side of the pass that follows the ray-tracing draw (C ABI, HIP kernels).
+/* rt_overlay.h -- the pass that follows the ray-tracing draw (C ABI, HIP kernels).
  *
  * After the fullscreen ray-tracing draw the reference rasterises nine textured meshes into the same framebuffer with
  * GL_DEPTH_TEST / GL_LEQUAL against the depth the ray tracer wrote through gl_FragDepth, blending disabled
  * (app/core/src/App.cpp:52-54,142-166).  The depth attachment is GL_DEPTH_COMPONENT24 (Framebuffer.cpp:10-12), so what
  * the rasterised fragments are tested against is a 24-bit value, not the float the shader wrote.  This header covers
- * that fixed-function half: the attachment value of a depth plane, and the depth-tested merge of fragments produced by
- * any rasteriser.  Rasterising the meshes themselves (vertex stage, coverage, interpolation, texturing:
- * Vert_PosNormTex.vert, Frag_LightingSimple.frag) is NOT part of this library.
+ * the attachment value of a depth plane, the depth-tested merge of fragments produced by any rasteriser, and the pass itself:
+ * rt_overlay_draw rasterises an indexed mesh once per instance matrix with the reference's vertex and fragment stages
+ * (Vert_PosNormTex.vert, Frag_LightingSimple.frag) into a colour plane and that 24-bit depth plane.
  */
 #ifndef RT_OVERLAY_H
 #define RT_OVERLAY_H
@@ -36,6 +36,39 @@ int rt_depth_to_attachment(const float *depth, uint32_t *depth24, size_t n_pixel
  * fragments and, between equal depths, the last drawn.  memory / stream as above. */
 int rt_overlay_composite(float *color, uint32_t *depth24, const float *frag_color, const uint32_t *frag_depth24,
                          const uint8_t *frag_mask, size_t n_pixels, int memory, void *stream);
+
+/* The mesh and texture of the overlay draws, resident on one HIP device.  vertices: [n_vert][8] floats = position, normal,
+ * texcoord, the reference's Vertex (GLUtils.hpp:29-34) with the attribute layout of App.cpp:65-69; indices: n_idx (a multiple
+ * of three) 32-bit indices, GL_TRIANGLES (App.cpp:163); texture_rgba: [tex_height][tex_width][4] bytes, row 0 = the row GL
+ * calls the bottom one (TextureFromFile flips the image before the upload, GLUtils.cpp:187-202).  All three are host arrays and
+ * are copied.  RT_ESCENE for an index beyond the vertex array. */
+typedef struct rt_overlay_mesh rt_overlay_mesh;
+int rt_overlay_mesh_create(const float *vertices, size_t n_vert, const uint32_t *indices, size_t n_idx,
+                           const uint8_t *texture_rgba, uint32_t tex_width, uint32_t tex_height, int device, rt_overlay_mesh **out);
+int rt_overlay_mesh_destroy(rt_overlay_mesh *mesh);
+
+/* Uniforms of the pass (App.cpp:152-162): viewProj (column-major, Camera::GetViewProj), the light (App.hpp:79-81), and per
+ * draw the matrices `world` and `worldIT` = transpose(inverse(world)), [n_draws][16] floats each, column-major, host memory. */
+typedef struct rt_overlay_pass {
+    float view_proj[16];
+    float light_dir[3], la[3], ld[3];
+    uint32_t n_draws;
+    const float *world, *world_it;
+} rt_overlay_pass;
+
+/* The draws of App.cpp:157-164 over `color` ([height][width][4] floats) and `depth24` ([height][width], the values of
+ * rt_depth_to_attachment), both updated in place; row 0 is the bottom row of the GL window, as in rt_target.  State as the
+ * reference sets it: back faces (clockwise in the window) culled, GL_LEQUAL depth test with depth writes, no blending, viewport =
+ * the whole frame, depth range [0, 1].  Coverage, depth and colour are those of the reference's GL on llvmpipe bit for bit: vertex
+ * stage, clipping against the six frustum planes, 1/256-pixel snapping with the left/bottom fill rule, plane equations and their
+ * evaluation, the fragment stage and the 8-bit bilinear GL_REPEAT lookup (pinned by read-backs of that GL; the arithmetic is
+ * stated in rt_raster.hip).  Limit: the texture is sampled from level 0 only; the reference asks for GL_LINEAR_MIPMAP_LINEAR
+ * (GLUtils.cpp:219), which differs where a pixel covers more than one texel -- its own mesh carries a single constant texture
+ * coordinate, where every lookup magnifies.  draws x triangles x 7 must stay below 2^32 (RT_ELIMIT).
+ * memory / stream as above; the mesh keeps scratch buffers (8 bytes per pixel and 176 bytes per possible triangle) between
+ * calls, so calls on one mesh must not overlap. */
+int rt_overlay_draw(rt_overlay_mesh *mesh, const rt_overlay_pass *pass, float *color, uint32_t *depth24,
+                    uint32_t width, uint32_t height, int memory, void *stream);
 
 #ifdef __cplusplus
 }

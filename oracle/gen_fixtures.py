@@ -310,6 +310,81 @@ def sky_size_fixture():
     print("sky sizes", os.path.getsize(os.path.join(GOLDEN, "ref_sky_sizes.npz")))
 
 
+def overlay_assets():
+    """overlay_assets.npz: the mesh and texture of the reference's raster pass as its loaders hand them to GL (App.cpp:71-76):
+    suzanne.obj through oracle.raster.load_obj, metal.png decoded to 8-bit RGBA and flipped (GLUtils.cpp:187-190)."""
+    from oracle import raster
+    from raytracer_amd.png import read_png_rgba
+    v, i = raster.load_obj("/root/reference/app/assets/suzanne.obj")
+    tex = read_png_rgba("/root/reference/app/assets/metal.png")[::-1].copy()
+    np.savez_compressed(os.path.join(GOLDEN, "overlay_assets.npz"), vertices=v, indices=i, texture=tex)
+    print("overlay assets", v.shape, i.shape, tex.shape, os.path.getsize(os.path.join(GOLDEN, "overlay_assets.npz")))
+    return v, i, tex
+
+
+def depth24_of(depth_readback: np.ndarray) -> np.ndarray:
+    """The 24-bit values behind a GL_FLOAT read-back of the depth attachment (value / (2^24 - 1) as a float)."""
+    return np.rint(depth_readback.astype(np.float64) * 16777215.0).astype(np.uint32)
+
+
+def overlay_fixtures():
+    """ref_overlay_soups.npz: triangle soups through the reference's raster shaders on llvmpipe (clipped by every frustum plane,
+    orthographic and perspective, texture coordinates that magnify); ref_overlay_suzanne_*.npz: the reference's nine draws of its
+    own mesh alone (over colour 0 / depth 1) and after the ray-tracing draw of the bunny scene (the whole frame of App::Render)."""
+    from oracle import raster
+    rng = np.random.default_rng(21)
+    F = np.float32
+    I = np.eye(4, dtype=F).reshape(-1)
+    rec = {}
+    tex = rng.integers(0, 256, (16, 8, 4), dtype=np.uint8)
+    rec["texture"] = tex
+    cam = Camera(eye=(0.3, 0.2, 1.0), at=(0, 0, 0), fovy=1.2, aspect=1.5, z_near=0.3, z_far=3.0)
+    for k in range(6):
+        n = 40
+        v = np.zeros((3 * n, 8), F)
+        spread, size = ((0.6, 0.39), (1.5, 1.2))[k >= 2]
+        c = rng.uniform(-spread, spread, (n, 1, 3)); v[:, :3] = (c + rng.uniform(-size, size, (n, 3, 3))).reshape(-1, 3)
+        v[:, 3:6] = rng.uniform(-1, 1, (3 * n, 3))
+        v[:, 6:8] = rng.uniform(0, 0.01, (3 * n, 2)) + rng.uniform(-2, 2, (n, 1, 2)).repeat(3, 1).reshape(-1, 2)
+        if k == 5:      # vertices on pixel centres and corners: edges through sample points
+            v[:, :2] = (rng.integers(0, 2 * 96 + 1, (3 * n, 2)) / F(96) - 1).astype(F) * np.array([1, 64 / 96], F)
+        vp = cam.view_proj().ravel() if k % 2 else I
+        words = raster.overlay_words(vp, [I], [I], (-1, -2, -0.5), (0.1, 0.2, 0.3), (0.9, 0.8, 0.7))
+        if k == 4:      # corners drawn from all over the soup: one texture coordinate for all, or the lookups would minify
+            v[:, 6:8] = (0.37, -1.21)
+        idx = rng.permutation(3 * n).astype(np.uint32) if k == 4 else np.arange(3 * n, dtype=np.uint32)
+        idx = idx[: 3 * (len(idx) // 3)]
+        o = refrun.run_overlay(v, idx, words, tex, 96, 64)
+        rec[f"vertices_{k}"] = v; rec[f"indices_{k}"] = idx; rec[f"words_{k}"] = words
+        rec[f"rgba_{k}"] = o["rgba"]; rec[f"depth24_{k}"] = depth24_of(o["depth"])
+        print("soup", k, "covered", int((rec[f"depth24_{k}"] != 0xFFFFFF).sum()))
+    np.savez_compressed(os.path.join(GOLDEN, "ref_overlay_soups.npz"), **rec)
+    print("overlay soups", os.path.getsize(os.path.join(GOLDEN, "ref_overlay_soups.npz")))
+
+    v, i, mtex = overlay_assets()
+    worlds, its = raster.reference_instances()
+    # (the mesh file is not centred: its vertices span x -3.9..-1.1, y 0.3..2.2, z 3.3..5.0, so the nine draws are centred at (-2.5 + 4 i, 5.25 + 4 j, 4.1))
+    # (power-of-two frame sizes: there the rasteriser's interpolated NDC of the ray-tracing draw equals the closed form the library uses by default)
+    views = {"front": (Camera(eye=(-2.5, 5.25, 13.0), at=(-2.5, 5.25, 4.1), aspect=2.0), (256, 128)),
+             "oblique": (Camera(eye=(6.0, 9.0, 10.0), at=(-2.5, 4.0, 4.1), aspect=1.0), (256, 256)),
+             "close": (Camera(eye=(-1.9, 5.55, 5.25), at=(-2.5, 5.25, 4.1), aspect=1.0), (128, 128)),      # inside the near range of one mesh
+             "through": (Camera(eye=(3.2, 1.6, -2.4), at=(-2.5, 1.25, 4.1), fovy=1.0, aspect=2.0), (256, 128))}   # the ray-traced scene in front of a mesh
+    scene, sky = bunny_scene(), fixture_sky()
+    for name, (cam, (w, h)) in views.items():
+        words = raster.overlay_words(cam.view_proj().ravel(), worlds, its, **raster.REFERENCE_LIGHT)
+        alone = refrun.run_overlay(v, i, words, mtex, w, h)
+        u = Uniforms.from_camera(cam, max_recursion_limit=2).pack()
+        traced = refrun.run_reference(scene, u, w, h, sky=sky)
+        frame = refrun.run_overlay(v, i, words, mtex, w, h, scene=scene, uniforms70=u, sky=sky)
+        out = dict(words=words, uniforms=u, sky=sky, size=np.array([w, h], np.int32),
+                   alone_rgba=alone["rgba"], alone_depth24=depth24_of(alone["depth"]),
+                   traced_rgba=traced["rgba"], traced_depth24=depth24_of(traced["depth"]),
+                   frame_rgba=frame["rgba"], frame_depth24=depth24_of(frame["depth"]))
+        path = os.path.join(GOLDEN, f"ref_overlay_suzanne_{name}.npz")
+        np.savez_compressed(path, **out)
+        print("overlay", name, "mesh pixels alone", int((out["alone_depth24"] != 0xFFFFFF).sum()), "in the frame", int((out["frame_depth24"] != out["traced_depth24"]).sum()), os.path.getsize(path))
+
+
 def accum8_fixture():
     """ref_accum8.npz: eight progressively blended frames (the blend factors 1/1 .. 1/8), 96 x 64."""
     scene, sky = bunny_scene(), fixture_sky()
@@ -334,6 +409,11 @@ def main():
         else:
             ndc_fixture(1280, 720, (440, 504), max_recursion_limit=5)
             ndc_fixture(3840, 2160, (1400, 1432), max_recursion_limit=2)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "overlay":
+        refrun.build()
+        assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+        overlay_fixtures()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sky":
         refrun.build()

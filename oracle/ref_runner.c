@@ -11,6 +11,11 @@
  * Buffer.cpp:3-14), draws the fullscreen triangle and dumps the RGBA32F colour attachment and the
  * 24-bit depth attachment.
  *
+ * Optionally (--overlay ...) it then draws the pass that follows in the reference's frame (App.cpp:142-166): indexed meshes with the
+ * reference's Vert_PosNormTex.vert / Frag_LightingSimple.frag (read from disk at run time as well), blending off, depth test
+ * GL_LEQUAL against what the ray-tracing draw left in the depth attachment, one draw per instance matrix, a mip-mapped RGBA8
+ * texture set up as GLUtils.cpp:193-224 does.  --no-rt skips the ray-tracing draw (colour 0, depth cleared to 1).
+ *
  * No reference source text is contained in this file; the shader text never enters the repo.
  * The binary is written to oracle/_ref/ (git-ignored).  It only works where /root/reference
  * exists (this container), so it is used to generate the data fixtures under tests/golden/ and to
@@ -71,7 +76,9 @@ int main(int argc, char **argv) {
     const char *vert = "/root/reference/app/assets/ray_tracer.vert";
     const char *frag = "/root/reference/app/assets/ray_tracer.frag";
     const char *ssbo[4] = {0, 0, 0, 0}, *uniforms = 0, *bounds = 0, *sky = 0, *times = 0, *out = "refout";
-    int sky_w = 0, sky_h = 0, blend = 1, bench = 0, quiet = 0;
+    int sky_w = 0, sky_h = 0, blend = 1, bench = 0, quiet = 0, no_rt = 0;
+    const char *ov_vert = "/root/reference/app/assets/Vert_PosNormTex.vert", *ov_frag = "/root/reference/app/assets/Frag_LightingSimple.frag";
+    const char *ov_vbo = 0, *ov_ibo = 0, *ov_uniforms = 0, *ov_tex = 0; int ov_tex_w = 0, ov_tex_h = 0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
 #define NEXT (i + 1 < argc ? argv[++i] : (fprintf(stderr, "missing value for %s\n", a), exit(2), ""))
@@ -84,6 +91,10 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--times")) times = NEXT; else if (!strcmp(a, "--out")) out = NEXT;
         else if (!strcmp(a, "--noblend")) blend = 0; else if (!strcmp(a, "--bench")) bench = atoi(NEXT);
         else if (!strcmp(a, "--quiet")) quiet = 1;
+        else if (!strcmp(a, "--overlay")) { ov_vbo = NEXT; ov_ibo = NEXT; ov_uniforms = NEXT; }
+        else if (!strcmp(a, "--overlay-tex")) { ov_tex = NEXT; ov_tex_w = atoi(NEXT); ov_tex_h = atoi(NEXT); }
+        else if (!strcmp(a, "--overlay-vert")) ov_vert = NEXT; else if (!strcmp(a, "--overlay-frag")) ov_frag = NEXT;
+        else if (!strcmp(a, "--no-rt")) no_rt = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
     void *glapi = dlopen("libglapi.so.0", RTLD_NOW | RTLD_GLOBAL);
@@ -150,6 +161,48 @@ int main(int argc, char **argv) {
     void (*pglReadPixels)(GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, void *) = gp("glReadPixels");
     void (*pglCullFace)(GLenum) = gp("glCullFace");
     GLenum (*pglGetError)(void) = gp("glGetError");
+    GLF(PFNGLGENBUFFERSPROC, glGenBuffers); GLF(PFNGLBINDBUFFERPROC, glBindBuffer); GLF(PFNGLBUFFERDATAPROC, glBufferData);
+    GLF(PFNGLENABLEVERTEXATTRIBARRAYPROC, glEnableVertexAttribArray); GLF(PFNGLVERTEXATTRIBPOINTERPROC, glVertexAttribPointer);
+    GLF(PFNGLGENERATEMIPMAPPROC, glGenerateMipmap);
+    void (*pglGenTextures)(GLsizei, GLuint *) = gp("glGenTextures");
+    void (*pglTexImage2D)(GLenum, GLint, GLint, GLsizei, GLsizei, GLint, GLenum, GLenum, const void *) = gp("glTexImage2D");
+    void (*pglTexParameteri)(GLenum, GLenum, GLint) = gp("glTexParameteri");
+    void (*pglDrawElements)(GLenum, GLsizei, GLenum, const void *) = gp("glDrawElements");
+    void (*pglClearDepth)(GLdouble) = gp("glClearDepth");
+
+    /* the overlay's program, mesh and texture */
+    GLuint ov_prog = 0, ov_vao = 0, ov_texid = 0; GLsizei ov_count = 0; float *OU = NULL; size_t ov_n_inst = 0;
+    if (ov_vbo) {
+        const char *vsrc2 = slurp(ov_vert, NULL), *fsrc2 = slurp(ov_frag, NULL);
+        GLuint vs2 = glCreateShader(GL_VERTEX_SHADER), fs2 = glCreateShader(GL_FRAGMENT_SHADER);
+        glShaderSource(vs2, 1, &vsrc2, NULL); glShaderSource(fs2, 1, &fsrc2, NULL); glCompileShader(vs2); glCompileShader(fs2);
+        GLint ok2 = 0; static char log2[16384];
+        glGetShaderiv(vs2, GL_COMPILE_STATUS, &ok2); if (!ok2) { glGetShaderInfoLog(vs2, sizeof log2, NULL, log2); fprintf(stderr, "overlay VS compile failed: %s\n", log2); return 4; }
+        glGetShaderiv(fs2, GL_COMPILE_STATUS, &ok2); if (!ok2) { glGetShaderInfoLog(fs2, sizeof log2, NULL, log2); fprintf(stderr, "overlay FS compile failed: %s\n", log2); return 4; }
+        ov_prog = glCreateProgram(); glAttachShader(ov_prog, vs2); glAttachShader(ov_prog, fs2); glLinkProgram(ov_prog);
+        glGetProgramiv(ov_prog, GL_LINK_STATUS, &ok2); if (!ok2) { glGetProgramInfoLog(ov_prog, sizeof log2, NULL, log2); fprintf(stderr, "overlay link failed: %s\n", log2); return 4; }
+        size_t nv, ni, nu; void *vd = slurp(ov_vbo, &nv), *id = slurp(ov_ibo, &ni); OU = slurp(ov_uniforms, &nu);
+        if (nu < 26 * 4 || (nu - 26 * 4) % (32 * 4)) { fprintf(stderr, "overlay uniform file: 26 words + 32 per instance\n"); return 6; }
+        ov_n_inst = (nu - 26 * 4) / (32 * 4); ov_count = (GLsizei)(ni / 4);
+        GLuint vbo, ibo; glGenVertexArrays(1, &ov_vao); glBindVertexArray(ov_vao);
+        glGenBuffers(1, &vbo); glBindBuffer(GL_ARRAY_BUFFER, vbo); glBufferData(GL_ARRAY_BUFFER, (GLsizeiptr)nv, vd, GL_STATIC_DRAW);
+        glGenBuffers(1, &ibo); glBindBuffer(GL_ELEMENT_ARRAY_BUFFER, ibo); glBufferData(GL_ELEMENT_ARRAY_BUFFER, (GLsizeiptr)ni, id, GL_STATIC_DRAW);
+        /* App.cpp:65-69: position, normal, texcoord of the 32-byte Vertex (GLUtils.hpp:29-34) */
+        glEnableVertexAttribArray(0); glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 32, (const void *)0);
+        glEnableVertexAttribArray(1); glVertexAttribPointer(1, 3, GL_FLOAT, GL_FALSE, 32, (const void *)12);
+        glEnableVertexAttribArray(2); glVertexAttribPointer(2, 2, GL_FLOAT, GL_FALSE, 32, (const void *)24);
+        glBindVertexArray(0);
+        if (ov_tex) {
+            size_t nt2; void *td = slurp(ov_tex, &nt2);
+            if (nt2 != (size_t)ov_tex_w * ov_tex_h * 4) { fprintf(stderr, "overlay texture file size mismatch\n"); return 6; }
+            pglGenTextures(1, &ov_texid); pglBindTexture(GL_TEXTURE_2D, ov_texid);
+            pglTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, ov_tex_w, ov_tex_h, 0, GL_RGBA, GL_UNSIGNED_BYTE, td);      /* GLUtils.cpp:193-202 */
+            glGenerateMipmap(GL_TEXTURE_2D);                                                                    /* GLUtils.cpp:215 */
+            pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR); pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR_MIPMAP_LINEAR);
+            pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_REPEAT); pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_REPEAT);
+            pglBindTexture(GL_TEXTURE_2D, 0);
+        }
+    }
 
     const char *vsrc = slurp(vert, NULL), *fsrc = slurp(frag, NULL);
     GLuint vs = glCreateShader(GL_VERTEX_SHADER), fs = glCreateShader(GL_FRAGMENT_SHADER);
@@ -225,7 +278,25 @@ int main(int argc, char **argv) {
         pglClear(GL_DEPTH_BUFFER_BIT);                                        /* App.cpp:98 */
         if (blend) glBlendColor(0.0f, 0.0f, 0.0f, 1.0f / (float)(k + 1));     /* App.cpp:104 */
         if (T) glUniform1f(UL("time"), T[k]);
-        pglDrawArrays(GL_TRIANGLES, 0, 3);                                    /* App.cpp:140 */
+        if (!no_rt) pglDrawArrays(GL_TRIANGLES, 0, 3);                        /* App.cpp:140 */
+        if (ov_prog) {                                                        /* App.cpp:142-166 */
+            pglDisable(GL_BLEND); pglEnable(GL_DEPTH_TEST);
+            glUseProgram(ov_prog); glBindVertexArray(ov_vao);
+            glActiveTexture(GL_TEXTURE0); pglBindTexture(GL_TEXTURE_2D, ov_texid);
+            glUniform1i(glGetUniformLocation(ov_prog, "texImage"), 0);
+            glUniformMatrix4fv(glGetUniformLocation(ov_prog, "viewProj"), 1, GL_FALSE, OU);
+            glUniform3fv(glGetUniformLocation(ov_prog, "light_dir"), 1, OU + 16);
+            glUniform3fv(glGetUniformLocation(ov_prog, "La"), 1, OU + 19);
+            glUniform3fv(glGetUniformLocation(ov_prog, "Ld"), 1, OU + 22);
+            for (size_t q = 0; q < ov_n_inst; q++) {
+                glUniformMatrix4fv(glGetUniformLocation(ov_prog, "world"), 1, GL_FALSE, OU + 26 + 32 * q);
+                glUniformMatrix4fv(glGetUniformLocation(ov_prog, "worldIT"), 1, GL_FALSE, OU + 26 + 32 * q + 16);
+                pglDrawElements(GL_TRIANGLES, ov_count, GL_UNSIGNED_INT, 0);
+            }
+            glUseProgram(prog); glBindVertexArray(vao);
+            if (cube) { glActiveTexture(GL_TEXTURE0); pglBindTexture(GL_TEXTURE_CUBE_MAP, cube); }
+            if (blend) pglEnable(GL_BLEND);
+        }
         pglFinish();
     }
     float *px = malloc(sizeof(float) * 4 * (size_t)g_w * g_h), *dz = malloc(sizeof(float) * (size_t)g_w * g_h);

@@ -144,3 +144,48 @@ def run_probe(frag_text: str, ssbo0: np.ndarray, width: int, height: int, *, sky
             args += ["--sky", ps, str(sky.shape[2]), str(sky.shape[1])]
         subprocess.run(args, check=True, capture_output=True, text=True)
         return np.fromfile(os.path.join(td, "o.rgba.f32"), dtype=np.float32).reshape(height, width, 4)
+
+
+def overlay_uniform_words(view_proj, worlds, world_its, light_dir, la, ld) -> np.ndarray:
+    """The overlay pass's uniforms as the runner reads them: viewProj[16] (column-major), light_dir[3], La[3], Ld[3], 1 pad word,
+    then world[16] + worldIT[16] per draw (App.cpp:152-163)."""
+    head = np.concatenate([np.asarray(view_proj, np.float32).reshape(16), np.asarray(light_dir, np.float32), np.asarray(la, np.float32), np.asarray(ld, np.float32), np.zeros(1, np.float32)])
+    inst = [np.concatenate([np.asarray(w, np.float32).reshape(16), np.asarray(wi, np.float32).reshape(16)]) for w, wi in zip(worlds, world_its)]
+    return np.concatenate([head] + inst).astype(np.float32)
+
+
+def run_overlay(vertices: np.ndarray, indices: np.ndarray, overlay_words: np.ndarray, texture: np.ndarray, width: int, height: int, *,
+                scene: dict | None = None, uniforms70=None, sky=None, frag_text: str | None = None, vert_text: str | None = None) -> dict:
+    """The reference's raster pass (its own two shader files unless probe texts are given) on llvmpipe: `vertices` [n,8] f32
+    (position, normal, texcoord), `indices` u32, `texture` [h,w,4] u8 (row 0 = bottom, as uploaded).  With `scene` the ray-tracing
+    draw runs first, as in the reference's frame; without it the pass draws over colour 0 / depth 1.  Returns rgba [H,W,4], depth [H,W]."""
+    if not available():
+        raise RuntimeError("reference runner not available (needs /root/reference and `make -C oracle ref`)")
+    with tempfile.TemporaryDirectory(prefix="rtovl_") as td:
+        def w(name, arr):
+            p = os.path.join(td, name)
+            np.ascontiguousarray(arr).tofile(p)
+            return p
+        args = [RUNNER, "--quiet", "--w", str(width), "--h", str(height), "--out", os.path.join(td, "o")]
+        args += ["--overlay", w("ov", np.asarray(vertices, np.float32)), w("oi", np.asarray(indices, np.uint32)), w("ou", np.asarray(overlay_words, np.float32))]
+        texture = np.ascontiguousarray(texture, np.uint8)
+        args += ["--overlay-tex", w("ot", texture), str(texture.shape[1]), str(texture.shape[0])]
+        for opt, text in (("--overlay-frag", frag_text), ("--overlay-vert", vert_text)):
+            if text is not None:
+                p = os.path.join(td, opt.strip("-") + ".glsl")
+                open(p, "w").write(text)
+                args += [opt, p]
+        if scene is None:
+            args += ["--no-rt", "--noblend"]
+        else:
+            args += ["--ssbo0", w("v", np.asarray(scene["vertices"], np.float32)), "--ssbo1", w("n", np.asarray(scene["normals"], np.float32)),
+                     "--ssbo2", w("t", np.asarray(scene["tri_refs"], np.uint32)), "--ssbo3", w("k", np.asarray(scene["nodes"], np.uint32))]
+            args += ["--bounds", w("b", np.concatenate([np.asarray(scene["bounds_min"], np.float32), np.asarray(scene["bounds_max"], np.float32)]))]
+            args += ["--uniforms", w("u", np.asarray(uniforms70, np.float32))]
+            if sky is not None:
+                sky = np.ascontiguousarray(sky, dtype=np.uint8)
+                args += ["--sky", w("s", sky), str(sky.shape[2]), str(sky.shape[1])]
+        subprocess.run(args, check=True, capture_output=True, text=True)
+        rgba = np.fromfile(os.path.join(td, "o.rgba.f32"), dtype=np.float32).reshape(height, width, 4)
+        depth = np.fromfile(os.path.join(td, "o.depth.f32"), dtype=np.float32).reshape(height, width)
+    return {"rgba": rgba, "depth": depth}

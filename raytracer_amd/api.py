@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "rt_manipulator_init", "rt_manipulator_set_camera", "rt_manipulator_update", "rt_manipulator_key", "rt_manipulator_mouse_move", "rt_manipulator_mouse_wheel",
     "rt_uniforms_set_camera", "rt_uniforms_set_portals",
     # include/rt_overlay.h
-    "rt_depth_to_attachment", "rt_overlay_composite",
+    "rt_depth_to_attachment", "rt_overlay_composite", "rt_overlay_mesh_create", "rt_overlay_mesh_destroy", "rt_overlay_draw",
     # include/rt_dist.h (bound in tests/test_gpu_dist_cabi.py)
     "rt_dist_make_id", "rt_dist_init", "rt_dist_rank", "rt_dist_world_size", "rt_dist_destroy", "rt_dist_scene_create", "rt_dist_skybox_set",
     "rt_dist_frame_bands", "rt_dist_gather_frame",
@@ -201,6 +201,67 @@ def overlay_composite(color, depth24, frag_color, frag_depth24, frag_mask=None, 
         raise ValueError("all planes must live in the same memory space")
     _check(L.rt_overlay_composite(pc, pz, pfc, pfz, pm, n, mem, stream))
     return color, depth24
+
+
+class rt_overlay_pass(C.Structure):
+    _fields_ = [("view_proj", C.c_float * 16), ("light_dir", C.c_float * 3), ("la", C.c_float * 3), ("ld", C.c_float * 3),
+                ("n_draws", C.c_uint32), ("world", C.c_void_p), ("world_it", C.c_void_p)]
+
+
+class OverlayMesh:
+    """rt_overlay_mesh: the mesh and texture of the reference's raster pass (App.cpp:65-76: m_Suzanne and m_metalTextureID) on a
+    HIP device.  vertices [n, 8] float32 (position, normal, texcoord), indices uint32 (triangles), texture [h, w, 4] uint8 with
+    row 0 = the bottom row (GLUtils.cpp:187-202)."""
+
+    def __init__(self, vertices, indices, texture, device: int = 0):
+        L = lib()
+        L.rt_overlay_mesh_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_overlay_mesh_destroy.argtypes = [C.c_void_p]
+        L.rt_overlay_draw.argtypes = [C.c_void_p, C.POINTER(rt_overlay_pass), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        v = np.ascontiguousarray(vertices, np.float32); i = np.ascontiguousarray(indices, np.uint32).reshape(-1); t = np.ascontiguousarray(texture, np.uint8)
+        if v.ndim != 2 or v.shape[1] != 8 or t.ndim != 3 or t.shape[2] != 4:
+            raise ValueError("vertices must be [n, 8] and the texture [h, w, 4]")
+        self._h = C.c_void_p()
+        _check(L.rt_overlay_mesh_create(v.ctypes.data, len(v), i.ctypes.data, len(i), t.ctypes.data, t.shape[1], t.shape[0], device, C.byref(self._h)))
+
+    def draw(self, color, depth24, view_proj, worlds, world_its, light_dir, la, ld, stream: int | None = None):
+        """rt_overlay_draw: the draws of App.cpp:147-164 over `color` ([h, w, 4] float32) and `depth24` ([h, w], 24-bit values), in
+        place.  Both numpy arrays (C-contiguous float32 / uint32) or both contiguous GPU tensors (depth24 int32 holding the values).
+        Matrices are column-major sequences of 16 floats."""
+        tensors = _is_tensor(color)
+        if tensors:
+            import torch
+            h, w = depth24.shape
+            if stream is None:
+                stream = torch.cuda.current_stream().cuda_stream
+        else:
+            if not (isinstance(color, np.ndarray) and color.dtype == np.float32 and color.flags.c_contiguous and isinstance(depth24, np.ndarray) and depth24.dtype == np.uint32 and depth24.flags.c_contiguous):
+                raise ValueError("color must be a C-contiguous float32 array and depth24 a C-contiguous uint32 array (they are updated in place)")
+            h, w = depth24.shape
+        pc, mem, _k1 = _plane_ptr(color, np.float32, 4 * h * w, "color")
+        pz, m2, _k2 = _plane_ptr(depth24, np.uint32, h * w, "depth24")
+        if mem != m2:
+            raise ValueError("both planes must live in the same memory space")
+        wm = np.ascontiguousarray(np.asarray(worlds, np.float32).reshape(-1, 16)); wi = np.ascontiguousarray(np.asarray(world_its, np.float32).reshape(-1, 16))
+        if len(wm) != len(wi):
+            raise ValueError("one worldIT per world matrix")
+        p = rt_overlay_pass()
+        p.view_proj[:] = [float(x) for x in np.asarray(view_proj, np.float32).reshape(16)]
+        p.light_dir[:] = [float(x) for x in np.asarray(light_dir, np.float32)]; p.la[:] = [float(x) for x in np.asarray(la, np.float32)]; p.ld[:] = [float(x) for x in np.asarray(ld, np.float32)]
+        p.n_draws = len(wm); p.world = wm.ctypes.data; p.world_it = wi.ctypes.data
+        _check(lib().rt_overlay_draw(self._h, C.byref(p), pc, pz, w, h, mem, stream))
+        return color, depth24
+
+    def close(self):
+        if self._h:
+            lib().rt_overlay_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 IDENTITY = np.eye(4, dtype=np.float32)

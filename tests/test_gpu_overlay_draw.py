@@ -1,0 +1,106 @@
+"""GPU tests of rt_overlay_draw (include/rt_overlay.h): the HIP raster pass against llvmpipe runs of the reference's raster
+shaders (fixtures), against the CPU restatement at larger sizes, and chained after the HIP ray tracer as in App::Render."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import raster
+from raytracer_amd import api
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SUZANNE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "ref_overlay_suzanne_*.npz")))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def split_words(words):
+    """(view_proj, worlds, world_its, light, la, ld) of the fixture's uniform words."""
+    n = (len(words) - 26) // 32
+    inst = words[26:].reshape(n, 32)
+    return words[:16], inst[:, :16], inst[:, 16:], words[16:19], words[19:22], words[22:25]
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_triangle_soups_match_llvmpipe(k):
+    z = np.load(os.path.join(GOLDEN, "ref_overlay_soups.npz"))
+    h, w = z[f"depth24_{k}"].shape
+    m = api.OverlayMesh(z[f"vertices_{k}"], z[f"indices_{k}"], z["texture"])
+    col = np.zeros((h, w, 4), np.float32); d24 = np.full((h, w), 0xFFFFFF, np.uint32)
+    m.draw(col, d24, *split_words(z[f"words_{k}"]))
+    m.close()
+    assert np.array_equal(d24, z[f"depth24_{k}"])
+    assert np.array_equal(bits(col), bits(z[f"rgba_{k}"]))
+
+
+@pytest.mark.parametrize("path", SUZANNE_FILES, ids=[os.path.basename(p)[20:-4] for p in SUZANNE_FILES])
+def test_reference_meshes_match_llvmpipe(path, bunny_octree):
+    """The nine draws alone; over llvmpipe's ray-traced frame; and over the HIP ray tracer's own frame (rt_render ->
+    rt_depth_to_attachment -> rt_overlay_draw), which must equal llvmpipe's finished frame of App::Render bit for bit."""
+    a = np.load(os.path.join(GOLDEN, "overlay_assets.npz")); z = np.load(path)
+    w, h = (int(v) for v in z["size"])
+    m = api.OverlayMesh(a["vertices"], a["indices"], a["texture"])
+    args = split_words(z["words"])
+    col = np.zeros((h, w, 4), np.float32); d24 = np.full((h, w), 0xFFFFFF, np.uint32)
+    m.draw(col, d24, *args)
+    assert np.array_equal(d24, z["alone_depth24"]) and np.array_equal(bits(col), bits(z["alone_rgba"]))
+    col = z["traced_rgba"].copy(); d24 = z["traced_depth24"].copy()
+    m.draw(col, d24, *args)
+    assert np.array_equal(d24, z["frame_depth24"]) and np.array_equal(bits(col), bits(z["frame_rgba"]))
+    sc = api.Scene.from_octree(bunny_octree); sc.set_skybox(z["sky"])
+    got = sc.render(z["uniforms"], w, h, planes=False)
+    sc.close()
+    col = np.ascontiguousarray(got["rgba"], np.float32); d24 = api.depth_to_attachment(got["depth"])
+    assert np.array_equal(d24, z["traced_depth24"]) and np.array_equal(bits(col), bits(z["traced_rgba"]))
+    m.draw(col, d24, *args)
+    m.close()
+    assert np.array_equal(d24, z["frame_depth24"]) and np.array_equal(bits(col), bits(z["frame_rgba"]))
+
+
+def test_4k_frame_on_device_equals_the_cpu_restatement():
+    """The reference's nine draws at 3840 x 2160 on device-resident planes against oracle/raster_oracle.c."""
+    import torch
+    a = np.load(os.path.join(GOLDEN, "overlay_assets.npz"))
+    from raytracer_amd.camera import Camera
+    w, h = 3840, 2160
+    cam = Camera(eye=(-2.5, 5.25, 11.0), at=(-2.5, 5.25, 4.1), aspect=w / h)
+    worlds, its = raster.reference_instances()
+    words = raster.overlay_words(cam.view_proj().ravel(), worlds, its, **raster.REFERENCE_LIGHT)
+    rng = np.random.default_rng(3)
+    col0 = rng.random((h, w, 4), dtype=np.float32); d0 = rng.integers(0xFF9800, 0x1000000, (h, w), dtype=np.uint32)      # around the meshes' depths: some of their fragments are hidden
+    want_c, want_d = col0.copy(), d0.copy()
+    raster.draw(a["vertices"], a["indices"], words, a["texture"], want_c, want_d)
+    assert (want_d != d0).sum() > 500_000
+    m = api.OverlayMesh(a["vertices"], a["indices"], a["texture"])
+    col = torch.from_numpy(col0).cuda(); d24 = torch.from_numpy(d0.astype(np.int32)).cuda()
+    for _ in range(2):      # the second call reuses the mesh's scratch; drawing twice over its own result changes nothing (LEQUAL, same fragments)
+        m.draw(col, d24, *split_words(words))
+    torch.cuda.synchronize()
+    m.close()
+    assert np.array_equal(d24.cpu().numpy().view(np.uint32), want_d)
+    assert np.array_equal(bits(col.cpu().numpy()), bits(want_c))
+
+
+def test_equal_depths_keep_the_last_draw_and_arguments_are_checked():
+    v = np.zeros((6, 8), np.float32)
+    v[:3, :3] = [[-0.5, -0.5, 0.25], [0.5, -0.5, 0.25], [0.0, 0.5, 0.25]]; v[3:, :3] = v[:3, :3]
+    v[:3, 3:6] = (0, 0, 1); v[3:, 3:6] = (1, 2, 0.5)      # the second triangle faces the light, the first does not
+    tex = np.full((2, 2, 4), 255, np.uint8)
+    I = np.eye(4, dtype=np.float32).reshape(-1)
+    col = np.zeros((32, 32, 4), np.float32); d24 = np.full((32, 32), 0xFFFFFF, np.uint32)
+    m = api.OverlayMesh(v, np.arange(6, dtype=np.uint32), tex)
+    m.draw(col, d24, I, [I], [I], (-1, -2, -0.5), (0, 0, 0), (1, 1, 1))
+    want_c = np.zeros_like(col); want_d = np.full_like(d24, 0xFFFFFF)
+    raster.draw(v, np.arange(6, dtype=np.uint32), raster.overlay_words(I, [I], [I], (-1, -2, -0.5), (0, 0, 0), (1, 1, 1)), tex, want_c, want_d)
+    assert np.array_equal(d24, want_d) and np.array_equal(bits(col), bits(want_c))
+    assert col[16, 16, 0] > 0.9      # lit: the later triangle's colour
+    with pytest.raises(api.RtError):
+        api.OverlayMesh(v, np.array([0, 1, 7], np.uint32), tex)
+    with pytest.raises(api.RtError):
+        api.OverlayMesh(v, np.array([0, 1], np.uint32), tex)
+    m.close()

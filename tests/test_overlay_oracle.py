@@ -1,0 +1,57 @@
+"""CPU tests: the restatement of the raster pass (oracle/raster_oracle.c) against llvmpipe runs of the reference's
+Vert_PosNormTex.vert / Frag_LightingSimple.frag with the state of App.cpp:46-56,142-166 (fixtures from oracle/gen_fixtures.py overlay)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import raster
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SUZANNE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "ref_overlay_suzanne_*.npz")))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_triangle_soups_bit_exact(k):
+    """Clipped by every frustum plane (k >= 2), perspective (odd k), shuffled draw order (4), edges through pixel centres (5)."""
+    z = np.load(os.path.join(GOLDEN, "ref_overlay_soups.npz"))
+    h, w = z[f"depth24_{k}"].shape
+    col = np.zeros((h, w, 4), np.float32); d24 = np.full((h, w), 0xFFFFFF, np.uint32)
+    raster.draw(z[f"vertices_{k}"], z[f"indices_{k}"], z[f"words_{k}"], z["texture"], col, d24)
+    assert np.array_equal(d24, z[f"depth24_{k}"])
+    assert np.array_equal(bits(col), bits(z[f"rgba_{k}"]))
+    assert (d24 != 0xFFFFFF).sum() > 1000
+
+
+@pytest.mark.parametrize("path", SUZANNE_FILES, ids=[os.path.basename(p)[20:-4] for p in SUZANNE_FILES])
+def test_reference_meshes_alone_and_in_the_frame(path):
+    """The nine draws of App.cpp:157-164 over an empty frame, and over the ray-traced frame llvmpipe produced (its colour and
+    24-bit depth are the inputs): both must reproduce llvmpipe's read-backs of the finished frame bit for bit."""
+    a = np.load(os.path.join(GOLDEN, "overlay_assets.npz")); z = np.load(path)
+    w, h = (int(v) for v in z["size"])
+    col = np.zeros((h, w, 4), np.float32); d24 = np.full((h, w), 0xFFFFFF, np.uint32)
+    raster.draw(a["vertices"], a["indices"], z["words"], a["texture"], col, d24)
+    assert np.array_equal(d24, z["alone_depth24"]) and np.array_equal(bits(col), bits(z["alone_rgba"]))
+    col = z["traced_rgba"].copy(); d24 = z["traced_depth24"].copy()
+    raster.draw(a["vertices"], a["indices"], z["words"], a["texture"], col, d24)
+    assert np.array_equal(d24, z["frame_depth24"]) and np.array_equal(bits(col), bits(z["frame_rgba"]))
+    assert (z["frame_depth24"] != z["traced_depth24"]).sum() > 1000
+
+
+def test_instance_matrices_and_light_of_the_reference():
+    worlds, its = raster.reference_instances()
+    assert len(worlds) == 9 and worlds[0][12:15].tolist() == [-4.0, 0.0, 0.0] and worlds[8][12:15].tolist() == [4.0, 8.0, 0.0]      # App.cpp:157-159
+    for w, it in zip(worlds, its):
+        m = w.reshape(4, 4).T.astype(np.float64)
+        assert np.allclose(np.linalg.inv(m).T, it.reshape(4, 4).T)
+
+
+def test_mesh_loader_shapes():
+    a = np.load(os.path.join(GOLDEN, "overlay_assets.npz"))
+    assert a["vertices"].shape == (507, 8) and a["indices"].shape == (2904,) and a["indices"].max() == 506      # 32 triangles + 468 quads
+    assert not a["vertices"][:, 6:8].any()      # the mesh file has no texture coordinates: every vertex gets (0, 0) (ObjParser.cpp:406)

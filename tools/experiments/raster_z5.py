@@ -1,0 +1,49 @@
+import itertools, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import refrun
+F = np.float32
+FRAG = "#version 430\nin vec3 vs_out_pos; in vec3 vs_out_norm; in vec2 vs_out_tex; out vec4 c;\nvoid main(){ c = vec4(gl_FragCoord.z, gl_FragCoord.w, vs_out_norm.x, 1.0); }\n"
+VERT = "#version 430\nlayout(location=0) in vec3 p; layout(location=1) in vec3 n; layout(location=2) in vec2 t; out vec3 vs_out_pos; out vec3 vs_out_norm; out vec2 vs_out_tex; uniform mat4 world; uniform mat4 worldIT; uniform mat4 viewProj;\nvoid main(){ gl_Position = vec4(p, t.x); vs_out_pos = p; vs_out_norm = n; vs_out_tex = vec2(0); }\n"
+def fma(a, b, c): return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(F)
+def sub2(kind, a, b, c, d):     # a*b - c*d
+    if kind == 0: return a * b - c * d
+    if kind == 1: return fma(a, b, -(c * d))
+    return fma(-c, d, a * b)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+I = np.eye(4, dtype=F)
+words = refrun.overlay_uniform_words(I, [I], [I], [0, 0, -1], [0.25] * 3, [0.5] * 3)
+tex = np.full((4, 4, 4), 255, np.uint8)
+W, H = 48, 32
+Xf = np.broadcast_to(np.arange(W, dtype=F)[None, :], (H, W)); Yf = np.broadcast_to(np.arange(H, dtype=F)[:, None], (H, W))
+score = {}
+n_done = 0
+while n_done < 30:
+    clip = np.ones((3, 4), F)
+    clip[:, :3] = rng.uniform(-1, 1, (3, 3)).astype(F)
+    v = np.zeros((3, 8), F); v[:, :3] = clip[:, :3]; v[:, 6] = clip[:, 3]; v[:, 3] = rng.uniform(-1, 1, 3)
+    o = refrun.run_overlay(v, np.array([0, 1, 2], np.uint32), words, tex, W, H, frag_text=FRAG, vert_text=VERT)
+    m = o["rgba"][..., 3] > 0
+    if m.sum() < 20: continue
+    n_done += 1
+    z = o["rgba"][..., 0]
+    xw = fma(clip[:, 0], F(W / 2), F(W / 2)); yw = fma(clip[:, 1], F(H / 2), F(H / 2)); zw = fma(clip[:, 2], F(0.5), F(0.5))
+    p = [1, 0, 2]
+    x, y, a = xw[p], yw[p], zw[p]
+    dx01, dy01 = x[0] - x[1], y[0] - y[1]; dx20, dy20 = x[2] - x[0], y[2] - y[0]
+    da01, da20 = a[0] - a[1], a[2] - a[0]
+    xc, yc = x[0] - F(0.5), y[0] - F(0.5)
+    for k_area, k_dx, k_dy, k_a0, pre in itertools.product(range(3), range(3), range(3), range(4), range(2)):
+        ooa = F(1.0) / sub2(k_area, dx01, dy20, dx20, dy01)
+        if pre == 0:
+            dadx = sub2(k_dx, da01, dy20 * ooa, da20, dy01 * ooa); dady = sub2(k_dy, da20, dx01 * ooa, da01, dx20 * ooa)
+        else:
+            dadx = sub2(k_dx, da01, dy20, da20, dy01) * ooa; dady = sub2(k_dy, da20, dx01, da01, dx20) * ooa
+        if k_a0 == 0: a0 = a[0] - (dadx * xc + dady * yc)
+        elif k_a0 == 1: a0 = a[0] - fma(dady, yc, dadx * xc)
+        elif k_a0 == 2: a0 = a[0] - fma(dadx, xc, dady * yc)
+        else: a0 = fma(-dady, yc, fma(-dadx, xc, a[0]))
+        zm = fma(dady, Yf, fma(dadx, Xf, a0))
+        score[(k_area, k_dx, k_dy, k_a0, pre)] = score.get((k_area, k_dx, k_dy, k_a0, pre), 0) + int((zm.view(np.uint32)[m] != z.view(np.uint32)[m]).sum())
+for k, s in sorted(score.items(), key=lambda kv: kv[1])[:10]:
+    print(k, s)
