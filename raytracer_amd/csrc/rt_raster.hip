@@ -29,7 +29,10 @@ namespace {
 
 constexpr unsigned BLOCK = 256;
 constexpr unsigned RT_FAN_MAX = 7;        // a triangle clipped by six planes has at most nine corners: seven triangles
-constexpr unsigned CHUNKS = 8;            // workgroups that share one slot's bounding box
+constexpr unsigned CHUNKS = 8;            // waves that share the bounding box of an ordinary triangle
+constexpr unsigned BIG_TILES = 64;        // a triangle whose bounding box has more 8 x 8 tiles than this is listed as big ...
+constexpr unsigned BIG_SPLIT = 128;       // ... and shared by this many waves: one wave's tiles are a chain of dependent loads and atomics
+constexpr uint32_t BIG_CAPACITY = 1u << 20;
 constexpr uint32_t NO_FRAGMENT = 0xFFFFFFFFu;
 
 struct OutVertex { float pos[4]; float win[4]; float attr[8]; };      // clip position; window x, y, z and 1/w; world position, normal, texcoord
@@ -38,7 +41,7 @@ struct RasterTri {
     int32_t fx[3], fy[3];              // corners relative to the pixel centres, in 1/256 pixel
     int32_t x_lo, x_hi, y_lo, y_hi;    // pixels to test (x_lo > x_hi: nothing to draw)
     float a0[10], dadx[10], dady[10];  // z, 1/w and the eight outputs times 1/w
-    uint32_t pad[2];
+    uint32_t big, pad;                 // big: listed in the big-triangle list (the ordinary walk skips it)
 };
 
 struct PassConstants {
@@ -102,7 +105,7 @@ __device__ __forceinline__ float plane_distance(const OutVertex &v, int plane) {
 // is dropped; the planes of a counter-clockwise triangle (v0, v1, v2) are set up from P = v1, Q = v0, R = v2 in float window
 // coordinates: ooa = 1 / (dx01*dy20 - dx20*dy01) with dx01 = P.x - Q.x, dx20 = R.x - P.x; dadx = da01*(dy20*ooa) - da20*(dy01*ooa),
 // dady = da20*(dx01*ooa) - da01*(dx20*ooa), a0 = a(P) - (dadx*(P.x - 0.5) + dady*(P.y - 0.5)); nothing fused.
-__device__ void setup_triangle(const PassConstants &C, const OutVertex &v0, const OutVertex &v1, const OutVertex &v2, RasterTri &T) {
+__device__ void setup_triangle(const PassConstants &C, const OutVertex &v0, const OutVertex &v1, const OutVertex &v2, RasterTri &T, uint32_t slot, uint32_t *big_list) {
     const OutVertex *v[3] = {&v0, &v1, &v2};
     int64_t fx[3], fy[3];
 #pragma unroll
@@ -112,7 +115,7 @@ __device__ void setup_triangle(const PassConstants &C, const OutVertex &v0, cons
         fx[i] = (int64_t)__builtin_rintf(x); fy[i] = (int64_t)__builtin_rintf(y);
         T.fx[i] = (int32_t)fx[i]; T.fy[i] = (int32_t)fy[i];
     }
-    T.x_lo = 1; T.x_hi = 0; T.y_lo = 1; T.y_hi = 0;
+    T.x_lo = 1; T.x_hi = 0; T.y_lo = 1; T.y_hi = 0; T.big = 0;
     const int64_t area = (fx[1] - fx[0]) * (fy[2] - fy[0]) - (fx[2] - fx[0]) * (fy[1] - fy[0]);
     if (!(area > 0)) return;
     const int64_t minx = min(fx[0], min(fx[1], fx[2])), maxx = max(fx[0], max(fx[1], fx[2])), miny = min(fy[0], min(fy[1], fy[2])), maxy = max(fy[0], max(fy[1], fy[2]));
@@ -134,19 +137,23 @@ __device__ void setup_triangle(const PassConstants &C, const OutVertex &v0, cons
         T.a0[k] = aP - (T.dadx[k] * xc + T.dady[k] * yc);
     }
     T.x_lo = (int32_t)x_lo; T.x_hi = (int32_t)x_hi; T.y_lo = (int32_t)y_lo; T.y_hi = (int32_t)y_hi;
+    if ((uint64_t)((x_hi - x_lo + 8) >> 3) * (uint64_t)((y_hi - y_lo + 8) >> 3) > BIG_TILES) {
+        const uint32_t at = atomicAdd(big_list, 1u);                 // big_list[0]: entries so far
+        if (at < BIG_CAPACITY) { big_list[1 + at] = slot; T.big = 1; }      // (a full list leaves the triangle to the ordinary walk)
+    }
 }
 
 // Clipping as the reference's GL does it: a triangle with a corner outside any of -w <= x, y, z <= w is clipped plane by plane
 // (x <= w, x >= -w, y <= w, y >= -w, z >= -w, z <= w; only the planes some corner violates), walking the polygon from its first
 // corner.  A new corner on an edge is a + t * (b - a) for the clip position and every output, a being the end of the edge nearer
 // to the plane, t = d_a / (d_a - d_b), not fused.  The polygon p0 .. pn-1 is drawn as the triangles (p[i-1], p[i], p0).
-__global__ __launch_bounds__(64) void setup_kernel(PassConstants C, const uint32_t *__restrict__ indices, const OutVertex *__restrict__ vs, RasterTri *__restrict__ slots) {
+__global__ __launch_bounds__(64) void setup_kernel(PassConstants C, const uint32_t *__restrict__ indices, const OutVertex *__restrict__ vs, RasterTri *__restrict__ slots, uint32_t *__restrict__ big_list) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= C.n_draws * C.n_tri) return;
     const uint32_t d = i / C.n_tri, t = i % C.n_tri;
     const OutVertex *base = vs + (size_t)d * C.n_vert;
     RasterTri *out = slots + (size_t)i * RT_FAN_MAX;
-    for (unsigned k = 0; k < RT_FAN_MAX; k++) { out[k].x_lo = 1; out[k].x_hi = 0; out[k].y_lo = 1; out[k].y_hi = 0; }
+    for (unsigned k = 0; k < RT_FAN_MAX; k++) { out[k].x_lo = 1; out[k].x_hi = 0; out[k].y_lo = 1; out[k].y_hi = 0; out[k].big = 0; }
     OutVertex a = base[indices[3 * t]], b = base[indices[3 * t + 1]], c = base[indices[3 * t + 2]];
     unsigned any_out = 0, all_out = 63;
     {
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(64) void setup_kernel(PassConstants C, const uint32
             any_out |= mask; all_out &= mask;
         }
     }
-    if (!any_out) { setup_triangle(C, a, b, c, out[0]); return; }
+    if (!any_out) { setup_triangle(C, a, b, c, out[0], i * RT_FAN_MAX, big_list); return; }
     if (all_out) return;
     OutVertex p0[9], p1[9];
     OutVertex *src = p0, *dst = p1;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(64) void setup_kernel(PassConstants C, const uint32
         n = m;
         OutVertex *sw = src; src = dst; dst = sw;
     }
-    for (int q = 2; q < n && q - 2 < (int)RT_FAN_MAX; q++) setup_triangle(C, src[q - 1], src[q], src[0], out[q - 2]);
+    for (int q = 2; q < n && q - 2 < (int)RT_FAN_MAX; q++) setup_triangle(C, src[q - 1], src[q], src[0], out[q - 2], i * RT_FAN_MAX + (uint32_t)(q - 2), big_list);
 }
 
 __device__ __forceinline__ uint32_t to_depth24(float z) {      // round-to-nearest-even(float(clamp(z, 0, 1) * 16777215))
@@ -200,40 +207,63 @@ __global__ __launch_bounds__(BLOCK) void key_init_kernel(const uint32_t *__restr
 }
 
 // A pixel centre belongs to the triangle when all three edge functions (integers, at the centre) are positive, or zero on a left
-// or a bottom edge.  z = fma(dady, y, fma(dadx, x, a0)) at the integer pixel coordinates.
-__global__ __launch_bounds__(64) void coverage_kernel(PassConstants C, const RasterTri *__restrict__ slots, unsigned long long *__restrict__ keys, uint32_t n_slots) {
+// or a bottom edge.  z = fma(dady, y, fma(dadx, x, a0)) at the integer pixel coordinates.  A wave takes the bounding box in tiles
+// of 8 x 8 pixels, one lane per pixel: an edge function at a pixel is its value at the tile's corner (the same for the whole wave)
+// plus the lane's own offset, and a tile that lies outside one of the edges altogether is skipped by the wave as a whole.
+__device__ void cover_tiles(const PassConstants &C, const RasterTri &T, uint32_t s, uint32_t first, uint32_t step, unsigned long long *__restrict__ keys) {
+    const int32_t lx = (int32_t)(threadIdx.x & 7u), ly = (int32_t)(threadIdx.x >> 3);
+    const int32_t x_lo = T.x_lo, x_hi = T.x_hi, y_lo = T.y_lo, y_hi = T.y_hi;
+    const uint32_t tiles_x = (uint32_t)(x_hi - x_lo + 8) >> 3, tiles = tiles_x * ((uint32_t)(y_hi - y_lo + 8) >> 3);
+    if (first >= tiles) return;
+    int64_t ex[3], ey[3], fx[3], fy[3], lane_part[3], lane_max[3]; bool incl[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { fx[i] = T.fx[i]; fy[i] = T.fy[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int j = (i + 1) % 3;
+        ex[i] = fx[j] - fx[i]; ey[i] = fy[j] - fy[i];
+        incl[i] = ey[i] < 0 || (ey[i] == 0 && ex[i] > 0);
+        lane_part[i] = ex[i] * (ly * 256) - ey[i] * (lx * 256);
+        lane_max[i] = (ex[i] > 0 ? ex[i] * (7 * 256) : 0) + (ey[i] < 0 ? -ey[i] * (7 * 256) : 0);
+    }
+    const float a0 = T.a0[0], dadx = T.dadx[0], dady = T.dady[0];
+    const unsigned long long order = (unsigned long long)(NO_FRAGMENT - 1u - s);      // later slots win between equal depths
+    for (uint32_t tile = first; tile < tiles; tile += step) {
+        const int32_t x0 = x_lo + (int32_t)(tile % tiles_x) * 8, y0 = y_lo + (int32_t)(tile / tiles_x) * 8;
+        int64_t base[3];
+        bool tile_out = false;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            base[k] = ex[k] * ((int64_t)y0 * 256 - fy[k]) - ey[k] * ((int64_t)x0 * 256 - fx[k]);
+            tile_out = tile_out || base[k] + lane_max[k] < 0;
+        }
+        if (tile_out) continue;
+        const int32_t x = x0 + lx, y = y0 + ly;
+        bool inside = x <= x_hi && y <= y_hi;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int64_t e = base[k] + lane_part[k];
+            inside = inside && (e > 0 || (e == 0 && incl[k]));
+        }
+        if (!inside) continue;
+        const float z = fmaf(dady, (float)y, fmaf(dadx, (float)x, a0));
+        const unsigned long long key = ((unsigned long long)to_depth24(z) << 32) | order;
+        unsigned long long *p = keys + (size_t)y * C.width + (size_t)x;
+        if (key < *p) atomicMin(p, key);
+    }
+}
+
+__global__ __launch_bounds__(64) void coverage_kernel(PassConstants C, const RasterTri *__restrict__ slots, unsigned long long *__restrict__ keys, uint32_t n_slots, const uint32_t *__restrict__ big_list) {
     for (uint32_t w = blockIdx.x; w < n_slots * CHUNKS; w += gridDim.x) {
-        const uint32_t s = w / CHUNKS, chunk = w % CHUNKS;
+        const uint32_t s = w / CHUNKS;
         const RasterTri &T = slots[s];
-        const int32_t x_lo = T.x_lo, x_hi = T.x_hi, y_lo = T.y_lo, y_hi = T.y_hi;
-        if (x_lo > x_hi) continue;
-        const uint32_t bw = (uint32_t)(x_hi - x_lo + 1), n = bw * (uint32_t)(y_hi - y_lo + 1);
-        if (chunk * 64u >= n) continue;
-        int64_t ex[3], ey[3], fx[3], fy[3]; bool incl[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) { fx[i] = T.fx[i]; fy[i] = T.fy[i]; }
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int j = (i + 1) % 3;
-            ex[i] = fx[j] - fx[i]; ey[i] = fy[j] - fy[i];
-            incl[i] = ey[i] < 0 || (ey[i] == 0 && ex[i] > 0);
-        }
-        const float a0 = T.a0[0], dadx = T.dadx[0], dady = T.dady[0];
-        const unsigned long long order = (unsigned long long)(NO_FRAGMENT - 1u - s);      // later slots win between equal depths
-        for (uint32_t i = chunk * 64u + threadIdx.x; i < n; i += 64u * CHUNKS) {
-            const int32_t x = x_lo + (int32_t)(i % bw), y = y_lo + (int32_t)(i / bw);
-            bool inside = true;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int64_t e = ex[k] * ((int64_t)y * 256 - fy[k]) - ey[k] * ((int64_t)x * 256 - fx[k]);
-                inside = inside && (e > 0 || (e == 0 && incl[k]));
-            }
-            if (!inside) continue;
-            const float z = fmaf(dady, (float)y, fmaf(dadx, (float)x, a0));
-            const unsigned long long key = ((unsigned long long)to_depth24(z) << 32) | order;
-            unsigned long long *p = keys + (size_t)y * C.width + (size_t)x;
-            if (key < *p) atomicMin(p, key);
-        }
+        if (T.x_lo > T.x_hi || T.big) continue;
+        cover_tiles(C, T, s, w % CHUNKS, CHUNKS, keys);
+    }
+    const uint32_t n_big = min(big_list[0], BIG_CAPACITY);
+    for (uint32_t w = blockIdx.x; w < n_big * BIG_SPLIT; w += gridDim.x) {
+        const uint32_t s = big_list[1 + w / BIG_SPLIT];
+        cover_tiles(C, slots[s], s, w % BIG_SPLIT, BIG_SPLIT, keys);
     }
 }
 
@@ -303,7 +333,7 @@ struct rt_overlay_mesh {
     int device = 0;
     uint32_t n_vert = 0, n_tri = 0, tex_w = 0, tex_h = 0;
     float *vertices = nullptr; uint32_t *indices = nullptr; uint8_t *texture = nullptr;
-    Buffer out_vertices, slots, keys, matrices, stage_color, stage_depth;      // grown on demand, kept between calls
+    Buffer out_vertices, slots, keys, matrices, big_list, stage_color, stage_depth;      // grown on demand, kept between calls
 };
 
 namespace {
@@ -354,7 +384,7 @@ extern "C" int rt_overlay_mesh_destroy(rt_overlay_mesh *m) {
     if (m->vertices) (void)hipFree(m->vertices);
     if (m->indices) (void)hipFree(m->indices);
     if (m->texture) (void)hipFree(m->texture);
-    m->out_vertices.release(); m->slots.release(); m->keys.release(); m->matrices.release(); m->stage_color.release(); m->stage_depth.release();
+    m->out_vertices.release(); m->slots.release(); m->keys.release(); m->matrices.release(); m->big_list.release(); m->stage_color.release(); m->stage_depth.release();
     delete m;
     return RT_OK;
 }
@@ -375,9 +405,10 @@ extern "C" int rt_overlay_draw(rt_overlay_mesh *m, const rt_overlay_pass *pass, 
     const size_t n_px = (size_t)width * height;
     // scratch of an earlier call may still be in use by work enqueued on another stream
     const size_t want_v = (size_t)pass->n_draws * m->n_vert * sizeof(OutVertex), want_s = (size_t)n_slots * sizeof(RasterTri), want_k = n_px * 8, want_m = (size_t)pass->n_draws * 32 * 4;
-    if (want_v > m->out_vertices.bytes || want_s > m->slots.bytes || want_k > m->keys.bytes || want_m > m->matrices.bytes ||
+    const size_t want_b = (size_t)(1u + (n_slots < BIG_CAPACITY ? (uint32_t)n_slots : BIG_CAPACITY)) * 4;
+    if (want_v > m->out_vertices.bytes || want_s > m->slots.bytes || want_k > m->keys.bytes || want_m > m->matrices.bytes || want_b > m->big_list.bytes ||
         (memory == RT_MEM_HOST && (n_px * 16 > m->stage_color.bytes || n_px * 4 > m->stage_depth.bytes))) HIP_OK(hipDeviceSynchronize());
-    HIP_OK(m->out_vertices.reserve(want_v)); HIP_OK(m->slots.reserve(want_s)); HIP_OK(m->keys.reserve(want_k)); HIP_OK(m->matrices.reserve(want_m));
+    HIP_OK(m->out_vertices.reserve(want_v)); HIP_OK(m->slots.reserve(want_s)); HIP_OK(m->keys.reserve(want_k)); HIP_OK(m->matrices.reserve(want_m)); HIP_OK(m->big_list.reserve(want_b));
     float4 *d_color = reinterpret_cast<float4 *>(color); uint32_t *d_depth = depth24;
     if (memory == RT_MEM_HOST) {
         HIP_OK(m->stage_color.reserve(n_px * 16)); HIP_OK(m->stage_depth.reserve(n_px * 4));
@@ -399,10 +430,12 @@ extern "C" int rt_overlay_draw(rt_overlay_mesh *m, const rt_overlay_pass *pass, 
     const unsigned px_grid = (unsigned)((n_px + BLOCK - 1) / BLOCK < 256u * 16u ? (n_px + BLOCK - 1) / BLOCK : 256u * 16u);
     const uint32_t n_v = pass->n_draws * m->n_vert, n_t = pass->n_draws * m->n_tri;
     vertex_kernel<<<(n_v + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(C, m->vertices, d_world, d_world_it, vs);
-    setup_kernel<<<(n_t + 63) / 64, 64, 0, st>>>(C, m->indices, vs, slots);
+    uint32_t *big_list = static_cast<uint32_t *>(m->big_list.p);
+    HIP_OK(hipMemsetAsync(big_list, 0, 4, st));
+    setup_kernel<<<(n_t + 63) / 64, 64, 0, st>>>(C, m->indices, vs, slots, big_list);
     key_init_kernel<<<px_grid, BLOCK, 0, st>>>(d_depth, keys, n_px);
     const unsigned long long work = n_slots * CHUNKS;
-    coverage_kernel<<<(unsigned)(work < 256ull * 64ull ? work : 256ull * 64ull), 64, 0, st>>>(C, slots, keys, (uint32_t)n_slots);
+    coverage_kernel<<<(unsigned)(work < 256ull * 64ull ? work : 256ull * 64ull), 64, 0, st>>>(C, slots, keys, (uint32_t)n_slots, big_list);
     resolve_kernel<<<px_grid, BLOCK, 0, st>>>(C, slots, keys, m->texture, d_color, d_depth);
     HIP_OK(hipGetLastError());
     if (memory == RT_MEM_HOST) {
