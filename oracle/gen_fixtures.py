@@ -380,6 +380,10 @@ def overlay_fixtures():
                    alone_rgba=alone["rgba"], alone_depth24=depth24_of(alone["depth"]),
                    traced_rgba=traced["rgba"], traced_depth24=depth24_of(traced["depth"]),
                    frame_rgba=frame["rgba"], frame_depth24=depth24_of(frame["depth"]))
+        if name == "through":      # three frames of App::Render: each ray-tracing draw blends over the FINISHED previous frame (mesh pixels included)
+            times = (np.arange(3, dtype=np.float32) / np.float32(60.0)).astype(np.float32)
+            three = refrun.run_overlay(v, i, words, mtex, w, h, scene=scene, uniforms70=u, sky=sky, times=times)
+            out.update(times=times, three_rgba=three["rgba"], three_depth24=depth24_of(three["depth"]))
         path = os.path.join(GOLDEN, f"ref_overlay_suzanne_{name}.npz")
         np.savez_compressed(path, **out)
         print("overlay", name, "mesh pixels alone", int((out["alone_depth24"] != 0xFFFFFF).sum()), "in the frame", int((out["frame_depth24"] != out["traced_depth24"]).sum()), os.path.getsize(path))

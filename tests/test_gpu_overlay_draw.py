@@ -62,6 +62,29 @@ def test_reference_meshes_match_llvmpipe(path, bunny_octree):
     assert np.array_equal(d24, z["frame_depth24"]) and np.array_equal(bits(col), bits(z["frame_rgba"]))
 
 
+def test_three_frames_of_app_render(bunny_octree):
+    """rt_render (blend 1/k over the finished previous frame) -> rt_depth_to_attachment -> rt_overlay_draw, three times, on device
+    planes: llvmpipe's third frame of the reference's whole Render() bit for bit."""
+    import torch
+    a = np.load(os.path.join(GOLDEN, "overlay_assets.npz")); z = np.load(os.path.join(GOLDEN, "ref_overlay_suzanne_through.npz"))
+    w, h = (int(v) for v in z["size"])
+    sc = api.Scene.from_octree(bunny_octree); sc.set_skybox(z["sky"])
+    m = api.OverlayMesh(a["vertices"], a["indices"], a["texture"])
+    col = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"); depth = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+    d24 = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rp = api.RenderPass(sc, w, h, col.data_ptr(), depth_ptr=depth.data_ptr(), stream=st)
+    for t in z["times"]:
+        u = z["uniforms"].copy(); u[20] = t
+        rp.Render(u)
+        api.depth_to_attachment(depth, out=d24)
+        m.draw(col, d24, *split_words(z["words"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(d24.cpu().numpy().view(np.uint32), z["three_depth24"])
+    assert np.array_equal(bits(col.cpu().numpy()), bits(z["three_rgba"]))
+    m.close(); sc.close()
+
+
 def test_4k_frame_on_device_equals_the_cpu_restatement():
     """The reference's nine draws at 3840 x 2160 on device-resident planes against oracle/raster_oracle.c."""
     import torch

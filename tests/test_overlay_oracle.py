@@ -43,6 +43,24 @@ def test_reference_meshes_alone_and_in_the_frame(path):
     assert (z["frame_depth24"] != z["traced_depth24"]).sum() > 1000
 
 
+def test_three_frames_of_the_whole_pass():
+    """App::Render three times with the camera at rest: the ray-tracing draw of frame k blends 1/k over the finished frame k-1
+    (rasterised mesh pixels included: the colour attachment persists, App.cpp:96-105), then the raster pass runs again."""
+    from oracle import oracle
+    from oracle.gen_fixtures import bunny_scene
+    a = np.load(os.path.join(GOLDEN, "overlay_assets.npz")); z = np.load(os.path.join(GOLDEN, "ref_overlay_suzanne_through.npz"))
+    w, h = (int(v) for v in z["size"])
+    osc = oracle.OracleScene(bunny_scene(), z["sky"])
+    col = None
+    for k, t in enumerate(z["times"]):
+        u = z["uniforms"].copy(); u[20] = t
+        o = osc.render(u, w, h, accum_index=k + 1, rgba=col, taps=False)
+        col = np.ascontiguousarray(o["rgba"], np.float32)
+        d24 = np.rint((np.clip(o["depth"], 0, 1) * np.float32(16777215.0)).astype(np.float32)).astype(np.uint32)
+        raster.draw(a["vertices"], a["indices"], z["words"], a["texture"], col, d24)
+    assert np.array_equal(d24, z["three_depth24"]) and np.array_equal(bits(col), bits(z["three_rgba"]))
+
+
 def test_instance_matrices_and_light_of_the_reference():
     worlds, its = raster.reference_instances()
     assert len(worlds) == 9 and worlds[0][12:15].tolist() == [-4.0, 0.0, 0.0] and worlds[8][12:15].tolist() == [4.0, 8.0, 0.0]      # App.cpp:157-159
