@@ -1,0 +1,80 @@
+"""TEST INFRASTRUCTURE, run by hand where /root/reference exists:  python -m oracle.fuzz_raster_vs_reference [--soups N] [--seed S]
+
+Random triangle soups -- frame sizes that are not powers of two, orthographic and perspective projections, triangles clipped by any
+subset of the six frustum planes, slivers, several draws with instance matrices, constant or magnifying texture coordinates -- through
+the reference's raster shaders on llvmpipe and through oracle/raster_oracle.c; coverage, 24-bit depth and colour must agree bit for bit.
+Pixels whose texture lookup minifies (not restated) are told apart by llvmpipe's own textureQueryLod and left out of the colour check."""
+import argparse
+import sys
+
+import numpy as np
+
+from oracle import raster, refrun
+from raytracer_amd.camera import Camera
+
+LOD_FRAG = ("#version 430\nin vec3 vs_out_pos; in vec3 vs_out_norm; in vec2 vs_out_tex; out vec4 c; layout(binding = 0) uniform sampler2D texImage;\n"
+            "void main(){ c = vec4(textureQueryLod(texImage, vs_out_tex), 0, 1); }\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--soups", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dump", default=None, help="directory that receives the inputs and both results of every mismatching soup (npz)")
+    a = ap.parse_args()
+    refrun.build()
+    rng = np.random.default_rng(a.seed)
+    F = np.float32
+    I = np.eye(4, dtype=F)
+    bad = 0
+    for k in range(a.soups):
+        w, h = [(96, 64), (100, 75), (121, 67), (160, 90), (64, 128)][rng.integers(0, 5)]
+        n = int(rng.integers(5, 60))
+        v = np.zeros((3 * n, 8), F)
+        spread, size = [(0.6, 0.4), (1.5, 1.2), (0.9, 0.05), (3.0, 3.0)][rng.integers(0, 4)]
+        c = rng.uniform(-spread, spread, (n, 1, 3)); v[:, :3] = (c + rng.uniform(-size, size, (n, 3, 3))).reshape(-1, 3)
+        if rng.uniform() < 0.2:      # slivers
+            v[2::3, :3] = v[1::3, :3] + rng.normal(0, 1e-3, (n, 3))
+        v[:, 3:6] = rng.uniform(-1, 1, (3 * n, 3))
+        if rng.uniform() < 0.5:
+            v[:, 6:8] = rng.uniform(-3, 3, 2)
+        else:
+            v[:, 6:8] = rng.uniform(0, 0.004, (3 * n, 2)) + rng.uniform(-2, 2, (n, 1, 2)).repeat(3, 1).reshape(-1, 2)
+        th, tw = [(4, 4), (16, 8), (7, 5), (32, 32), (8, 5), (6, 16), (1, 1), (3, 64)][rng.integers(0, 8)]
+        tex = rng.integers(0, 256, (th, tw, 4), dtype=np.uint8)
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            vp = I.reshape(-1)
+        else:
+            e = rng.normal(size=3); e = e / np.linalg.norm(e) * rng.uniform(0.5, 4.0)
+            cam = Camera(eye=tuple(float(x) for x in e), at=tuple(rng.uniform(-0.3, 0.3, 3)), fovy=float(rng.uniform(0.4, 2.0)), aspect=w / h,
+                         z_near=float(10 ** rng.uniform(-2, -0.2)), z_far=float(10 ** rng.uniform(0.5, 2)))
+            vp = cam.view_proj().ravel()
+        n_draws = int(rng.integers(1, 4))
+        worlds, its = [], []
+        for _ in range(n_draws):
+            m = np.eye(4); m[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0] * rng.uniform(0.5, 1.5); m[:3, 3] = rng.uniform(-0.5, 0.5, 3)
+            worlds.append(m.T.astype(F).reshape(-1)); its.append(np.linalg.inv(m).astype(F).reshape(-1))      # column-major world; transpose(inverse) column-major = inverse row-major
+        words = raster.overlay_words(vp, worlds, its, rng.uniform(-1, 1, 3), rng.uniform(0, 0.5, 3), rng.uniform(0, 1, 3))
+        idx = np.arange(3 * n, dtype=np.uint32)
+        o = refrun.run_overlay(v, idx, words, tex, w, h)
+        lod = refrun.run_overlay(v, idx, words, tex, w, h, frag_text=LOD_FRAG)["rgba"]
+        col = np.zeros((h, w, 4), F); d24 = np.full((h, w), 0xFFFFFF, np.uint32)
+        raster.draw(v, idx, words, tex, col, d24)
+        ref24 = np.rint(o["depth"].astype(np.float64) * 16777215.0).astype(np.uint32)
+        magnified = ~(lod[..., 1] > 0)
+        nd = int((d24 != ref24).sum())
+        nc = int(((col.view(np.uint32) != o["rgba"].view(np.uint32)).any(-1) & magnified).sum())
+        if nd or nc:
+            bad += 1
+            print(f"MISMATCH soup {k} seed {a.seed} {w}x{h} n {n} draws {n_draws} kind {kind}: depth {nd} colour {nc}", flush=True)
+            if a.dump:
+                np.savez(f"{a.dump}/raster_mismatch_{a.seed}_{k}.npz", v=v, idx=idx, words=words, tex=tex, size=np.array([w, h]), ref_rgba=o["rgba"], ref_depth24=ref24, rgba=col, depth24=d24, lod=lod)
+        if k % 20 == 19:
+            print(f"{k + 1} soups, {bad} mismatching", flush=True)
+    print(f"done: {a.soups} soups, {bad} mismatching")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

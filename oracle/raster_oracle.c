@@ -22,13 +22,15 @@
  *   - depth24 = round-to-nearest-even(float(clamp(z, 0, 1) * 16777215.0f));
  *   - fragment stage: dot(a, b) = (a.z*b.z + a.y*b.y) + a.x*b.x, normalize(v) = v * (1 / sqrt(dot(v, v))), clamp = min(max(., 0), 1),
  *     nothing fused;
- *   - texture: coordinate * size * 256 rounded to nearest, minus 128: texel = value >> 8 (wrapped), weight = value & 255;
+ *   - texture: per axis, a power-of-two size gives (c * size) * 256, any other size takes the fraction first, f = min(c - floor(c),
+ *     0.99999994), and gives (f * size) * 256; rounded to nearest even, minus 128: texel = value >> 8 (wrapped), weight = value & 255;
  *     8-bit lerp(a, b, w) = a + (((b - a) * w + 128) >> 8) along x, then along y; result * (1 / 255).
  *   - clipping: a triangle with a vertex outside any of the six planes -w <= x, y, z <= w is clipped plane by plane (x <= w, x >= -w,
  *     y <= w, y >= -w, z >= -w, z <= w; only the planes some vertex violates), walking the polygon from its first vertex; a new
  *     vertex on an edge is a + t * (b - a) for the clip position and every output, a being the end of the edge nearer to the
  *     plane (|d_a| < |d_b|, d = w -+ coordinate) whether it is inside or outside, t = d_a / (d_a - d_b), not fused, and its window position is ((clip * (1/w)) * scale) + translate, not fused either; the polygon (p0 .. pn-1) is
- *     drawn as the triangles (p[i-1], p[i], p0).
+ *     drawn as the triangles (p[i-1], p[i], p0), each culled first by the sign of (v0 - v2) x (v1 - v2) in float window coordinates
+ *     (the pieces of a clipped triangle only; negative = clockwise is dropped, zero passes on to the snapped-coordinate test).
  * Only level 0 of the texture is sampled (the reference's own mesh carries one constant texture coordinate, which
  * selects magnification); minified lookups are outside what this restatement pins.
  */
@@ -75,8 +77,16 @@ typedef struct {
 static int lerp8(int a, int b, int w) { return a + (((b - a) * w + 128) >> 8); }
 static int wrap(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
 
+/* Texel coordinate in 1/256 texel.  A power-of-two size scales the coordinate itself (GL_REPEAT then wraps the integer texel index);
+ * any other size takes the fraction of the coordinate first (kept below 1) and scales that.  Rounded to nearest even. */
+static int texel_fixed(float c, int size) {
+    if ((size & (size - 1)) == 0) return (int)lrintf(c * (float)size * 256.0f);
+    const float f = fminf(c - floorf(c), 0.99999994f);
+    return (int)lrintf(f * (float)size * 256.0f);
+}
+
 static void sample_texture(const target *t, float u, float v, float out[4]) {
-    const int su = (int)lrintf(u * (float)t->tex_w * 256.0f) - 128, sv = (int)lrintf(v * (float)t->tex_h * 256.0f) - 128;
+    const int su = texel_fixed(u, t->tex_w) - 128, sv = texel_fixed(v, t->tex_h) - 128;
     const int i0 = wrap(su >> 8, t->tex_w), i1 = wrap((su >> 8) + 1, t->tex_w), j0 = wrap(sv >> 8, t->tex_h), j1 = wrap((sv >> 8) + 1, t->tex_h);
     const int wu = su & 255, wv = sv & 255;
     for (int c = 0; c < 4; c++) {
@@ -229,8 +239,15 @@ int raster_oracle_draw(const float *vertices, size_t n_vert, const uint32_t *ind
                 n = clip_plane(src, n, pl, dst, width, height);
                 out_vertex *sw = src; src = dst; dst = sw;
             }
-            /* the polygon as a fan that keeps its first vertex last in every triangle */
-            for (int q = 2; q < n; q++) raster_triangle(&t, &src[q - 1], &src[q], &src[0], id);
+            /* the polygon as a fan that keeps its first vertex last in every triangle; a clipped triangle's pieces are culled by the sign
+               of their area in FLOAT window coordinates, e x f with e = v0 - v2, f = v1 - v2 (zero passes), before the rasteriser applies
+               its own test in snapped coordinates */
+            for (int q = 2; q < n; q++) {
+                const float *a = src[q - 1].win, *b = src[q].win, *c = src[0].win;
+                const float ex = a[0] - c[0], ey = a[1] - c[1], fx = b[0] - c[0], fy = b[1] - c[1];
+                if (ex * fy - ey * fx < 0.0f) continue;
+                raster_triangle(&t, &src[q - 1], &src[q], &src[0], id);
+            }
         }
     }
     free(vs);

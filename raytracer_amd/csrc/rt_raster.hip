@@ -146,7 +146,8 @@ __device__ void setup_triangle(const PassConstants &C, const OutVertex &v0, cons
 // Clipping as the reference's GL does it: a triangle with a corner outside any of -w <= x, y, z <= w is clipped plane by plane
 // (x <= w, x >= -w, y <= w, y >= -w, z >= -w, z <= w; only the planes some corner violates), walking the polygon from its first
 // corner.  A new corner on an edge is a + t * (b - a) for the clip position and every output, a being the end of the edge nearer
-// to the plane, t = d_a / (d_a - d_b), not fused.  The polygon p0 .. pn-1 is drawn as the triangles (p[i-1], p[i], p0).
+// to the plane, t = d_a / (d_a - d_b), not fused.  The polygon p0 .. pn-1 is drawn as the triangles (p[i-1], p[i], p0); these pieces
+// (not unclipped triangles) pass a cull test in float window coordinates before the snapped-coordinate one.
 __global__ __launch_bounds__(64) void setup_kernel(PassConstants C, const uint32_t *__restrict__ indices, const OutVertex *__restrict__ vs, RasterTri *__restrict__ slots, uint32_t *__restrict__ big_list) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= C.n_draws * C.n_tri) return;
@@ -194,7 +195,13 @@ __global__ __launch_bounds__(64) void setup_kernel(PassConstants C, const uint32
         n = m;
         OutVertex *sw = src; src = dst; dst = sw;
     }
-    for (int q = 2; q < n && q - 2 < (int)RT_FAN_MAX; q++) setup_triangle(C, src[q - 1], src[q], src[0], out[q - 2], i * RT_FAN_MAX + (uint32_t)(q - 2), big_list);
+    for (int q = 2; q < n && q - 2 < (int)RT_FAN_MAX; q++) {
+        // the pieces of a clipped triangle are culled first by the sign of (v0 - v2) x (v1 - v2) in FLOAT window coordinates (zero passes)
+        const float *a = src[q - 1].win, *b = src[q].win, *c = src[0].win;
+        const float ex = a[0] - c[0], ey = a[1] - c[1], fx = b[0] - c[0], fy = b[1] - c[1];
+        if (ex * fy - ey * fx < 0.0f) continue;
+        setup_triangle(C, src[q - 1], src[q], src[0], out[q - 2], i * RT_FAN_MAX + (uint32_t)(q - 2), big_list);
+    }
 }
 
 __device__ __forceinline__ uint32_t to_depth24(float z) {      // round-to-nearest-even(float(clamp(z, 0, 1) * 16777215))
@@ -270,12 +277,19 @@ __global__ __launch_bounds__(64) void coverage_kernel(PassConstants C, const Ras
 __device__ __forceinline__ int lerp8(int a, int b, int w) { return a + (((b - a) * w + 128) >> 8); }
 __device__ __forceinline__ int wrap(int i, int n) { const int r = i % n; return r < 0 ? r + n : r; }
 
-// GL_LINEAR with GL_REPEAT on level 0 of an RGBA8 texture, in the 8-bit fixed point of the reference's GL: coordinate * size * 256
-// rounded to nearest, minus 128, gives texel (>> 8) and weight (& 255); lerp(a, b, w) = a + (((b - a) * w + 128) >> 8) along x,
-// then along y; the result times 1/255.
+// Texel coordinate in 1/256 texel, as the reference's GL computes it per axis: a power-of-two size scales the coordinate itself
+// (GL_REPEAT then wraps the integer texel index); any other size takes the fraction of the coordinate first (kept below 1) and scales
+// that.  Rounded to nearest even.  (A NaN ends at the constants; a coordinate beyond the integer range is clamped.)
+__device__ __forceinline__ int texel_fixed(float c, int size) {
+    if ((size & (size - 1)) == 0) return (int)__builtin_rintf(fminf(fmaxf(c * (float)size * 256.0f, -2.0e9f), 2.0e9f));
+    const float f = fminf(c - floorf(c), 0.99999994f);
+    return (int)__builtin_rintf(f * (float)size * 256.0f);
+}
+
+// GL_LINEAR with GL_REPEAT on level 0 of an RGBA8 texture, in the 8-bit fixed point of the reference's GL: the texel coordinate minus
+// 128 gives texel (>> 8) and weight (& 255); lerp(a, b, w) = a + (((b - a) * w + 128) >> 8) along x, then along y; the result times 1/255.
 __device__ void sample_texture(const uint8_t *__restrict__ tex, int tw, int th, float u, float v, float *out) {
-    const float fu = fminf(fmaxf(u * (float)tw * 256.0f, -2.0e9f), 2.0e9f), fv = fminf(fmaxf(v * (float)th * 256.0f, -2.0e9f), 2.0e9f);
-    const int su = (int)__builtin_rintf(fu) - 128, sv = (int)__builtin_rintf(fv) - 128;
+    const int su = texel_fixed(u, tw) - 128, sv = texel_fixed(v, th) - 128;
     const int i0 = wrap(su >> 8, tw), i1 = wrap((su >> 8) + 1, tw), j0 = wrap(sv >> 8, th), j1 = wrap((sv >> 8) + 1, th);
     const int wu = su & 255, wv = sv & 255;
     const uchar4 a = reinterpret_cast<const uchar4 *>(tex)[(size_t)j0 * tw + i0], b = reinterpret_cast<const uchar4 *>(tex)[(size_t)j0 * tw + i1];

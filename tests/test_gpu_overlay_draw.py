@@ -127,3 +127,44 @@ def test_equal_depths_keep_the_last_draw_and_arguments_are_checked():
     with pytest.raises(api.RtError):
         api.OverlayMesh(v, np.array([0, 1], np.uint32), tex)
     m.close()
+
+
+def test_random_soups_equal_the_cpu_restatement():
+    """Random soups (non-power-of-two frames and textures, perspective, several draws, slivers, clipping) on the GPU against
+    oracle/raster_oracle.c, which the by-hand run `python -m oracle.fuzz_raster_vs_reference` holds to llvmpipe."""
+    from raytracer_amd.camera import Camera
+    rng = np.random.default_rng(11)
+    F = np.float32
+    I = np.eye(4, dtype=F)
+    for k in range(24):
+        w, h = [(96, 64), (100, 75), (121, 67), (333, 190), (64, 128)][rng.integers(0, 5)]
+        n = int(rng.integers(5, 80))
+        v = np.zeros((3 * n, 8), F)
+        spread, size = [(0.6, 0.4), (1.5, 1.2), (0.9, 0.05), (3.0, 3.0)][rng.integers(0, 4)]
+        c = rng.uniform(-spread, spread, (n, 1, 3)); v[:, :3] = (c + rng.uniform(-size, size, (n, 3, 3))).reshape(-1, 3)
+        if k % 5 == 0:
+            v[2::3, :3] = v[1::3, :3] + rng.normal(0, 1e-3, (n, 3))
+        v[:, 3:6] = rng.uniform(-1, 1, (3 * n, 3))
+        v[:, 6:8] = rng.uniform(-3, 3, (3 * n, 2)) if k % 3 else rng.uniform(-3, 3, 2)      # (level 0 on both sides, whatever the footprint)
+        th, tw = [(4, 4), (16, 8), (7, 5), (32, 32), (8, 5), (6, 16), (1, 1), (3, 64)][rng.integers(0, 8)]
+        tex = rng.integers(0, 256, (th, tw, 4), dtype=np.uint8)
+        if k % 2:
+            e = rng.normal(size=3); e = e / np.linalg.norm(e) * rng.uniform(0.5, 4.0)
+            vp = Camera(eye=tuple(float(x) for x in e), at=tuple(rng.uniform(-0.3, 0.3, 3)), fovy=float(rng.uniform(0.4, 2.0)), aspect=w / h,
+                        z_near=float(10 ** rng.uniform(-2, -0.2)), z_far=float(10 ** rng.uniform(0.5, 2))).view_proj().ravel()
+        else:
+            vp = I.reshape(-1)
+        worlds, its = [], []
+        for _ in range(int(rng.integers(1, 4))):
+            m = np.eye(4); m[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0] * rng.uniform(0.5, 1.5); m[:3, 3] = rng.uniform(-0.5, 0.5, 3)
+            worlds.append(m.T.astype(F).reshape(-1)); its.append(np.linalg.inv(m).astype(F).reshape(-1))
+        light, la, ld = rng.uniform(-1, 1, 3), rng.uniform(0, 0.5, 3), rng.uniform(0, 1, 3)
+        idx = np.arange(3 * n, dtype=np.uint32)
+        want_c = rng.random((h, w, 4), dtype=np.float32); want_d = rng.integers(0x800000, 0x1000000, (h, w), dtype=np.uint32)
+        col, d24 = want_c.copy(), want_d.copy()
+        raster.draw(v, idx, raster.overlay_words(vp, worlds, its, light, la, ld), tex, want_c, want_d)
+        m = api.OverlayMesh(v, idx, tex)
+        m.draw(col, d24, vp, worlds, its, light, la, ld)
+        m.close()
+        assert np.array_equal(d24, want_d), k
+        assert np.array_equal(bits(col), bits(want_c)), k
