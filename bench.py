@@ -113,6 +113,44 @@ def self_launch(args) -> int:
     return 0 if line is not None else 1
 
 
+def raster_pass_timing(width, height, device):
+    """The pass that follows the ray-tracing draw in the reference's frame (App.cpp:142-166: nine draws of its mesh, depth-tested
+    against the ray tracer's depth), timed on device planes at the benchmark's frame size: an extra of the JSON line, not part of `value`."""
+    import numpy as np
+    import torch
+    from raytracer_amd import api
+    from raytracer_amd.camera import Camera
+    assets = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "overlay_assets.npz")
+    if not os.path.exists(assets):
+        return None
+    z = np.load(assets)
+    worlds, its = [], []
+    for i in (-1, 0, 1):                       # App.cpp:157-162
+        for j in (-1, 0, 1):
+            t = np.array([4.0 * i, 4.0 + 4.0 * j, 0.0], np.float32)
+            w = np.eye(4, dtype=np.float32); w[3, :3] = t
+            it = np.eye(4, dtype=np.float32); it[:3, 3] = -t
+            worlds.append(w.reshape(16)); its.append(it.reshape(16))
+    cam = Camera(eye=(-2.5, 5.25, 11.0), at=(-2.5, 5.25, 4.1), aspect=width / height)
+    mesh = api.OverlayMesh(z["vertices"], z["indices"], z["texture"], device=device)
+    dev = torch.device("cuda", device)
+    col = torch.zeros((height, width, 4), dtype=torch.float32, device=dev); d24 = torch.full((height, width), 0xFFFFFF, dtype=torch.int32, device=dev)
+    args_ = (cam.view_proj().ravel(), worlds, its, (-1.0, -2.0, -0.5), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))      # light: App.hpp:79-81
+    for _ in range(3):
+        mesh.draw(col, d24, *args_)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    calls = 20
+    t0.record()
+    for _ in range(calls):
+        mesh.draw(col, d24, *args_)
+    t1.record(); torch.cuda.synchronize()
+    covered = int((d24 != 0xFFFFFF).sum())
+    mesh.close()
+    return {"what": "rt_overlay_draw: the reference's nine draws of its textured mesh after the ray-tracing draw, device planes", "ms_per_call": round(t0.elapsed_time(t1) / calls, 4),
+            "triangles": 9 * int(len(z["indices"]) // 3), "covered_pixels": covered, "width": width, "height": height}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -394,6 +432,8 @@ def main():
             ns["what"] = ("BASELINE.json configs[3] (>= 1 M primitives, deep octree, incoherent secondary rays, 4K, tile-split over the same ranks), measured like the "
                           "headline workload; " + ("octree children visited nearest first with the reference shader's results" if order != "reference" else "the same in the shader's own child order"))
             out[name] = ns
+    if rank == 0 and not args.no_north_star:
+        out["raster_pass"] = raster_pass_timing(args.width, args.height, local_rank)
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
