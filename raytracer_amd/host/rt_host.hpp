@@ -6,6 +6,8 @@
 //   RayTracePass replaces what App keeps for the ray-tracing draw: the four storage buffers (App.cpp:23-26), the
 //               skybox texture (Skybox.cpp:46-57), the accumulation counter (App.cpp:29,90-92,104-105,209) and the
 //               draw itself (App.cpp:107-140)
+//   RasterPass  replaces what App keeps for the pass after it: the mesh object and texture (App.cpp:65-76), the light
+//               (App.hpp:79-81) and the nine draws (App.cpp:142-166)
 //   Camera, Portal, CameraManipulator mirror the classes of the same names (Camera.hpp:5-56, Portal.hpp,
 //               CameraManipulator.hpp:12-65) on include/rt_camera.h: binary32 arithmetic in glm's operation order
 //
@@ -162,6 +164,47 @@ private:
     }
     rt_scene *m_scene = nullptr;
     uint32_t m_still_frame_counter = 1;            // App.cpp:29
+};
+
+// The raster pass after the ray-tracing draw (App.cpp:142-166) on the same device planes: the mesh (interleaved Vertex =
+// position, normal, texcoord: GLUtils.hpp:29-34) and its RGBA8 texture (row 0 = bottom row, as TextureFromFile uploads it),
+// the light, and one draw per instance matrix -- by default the reference's nine translations (App.cpp:157-159).
+class RasterPass {
+public:
+    RasterPass(const float *vertices, size_t n_vert, const uint32_t *indices, size_t n_idx, const uint8_t *texture_rgba, uint32_t tex_w, uint32_t tex_h, int device = 0) {
+        check(rt_overlay_mesh_create(vertices, n_vert, indices, n_idx, texture_rgba, tex_w, tex_h, device, &m_mesh));
+        for (int i = -1; i <= 1; ++i)
+            for (int j = -1; j <= 1; ++j) AddInstance({4.0f * (float)i, 4.0f + 4.0f * (float)j, 0.0f});
+    }
+    ~RasterPass() { (void)rt_overlay_mesh_destroy(m_mesh); }
+    RasterPass(const RasterPass &) = delete;
+    RasterPass &operator=(const RasterPass &) = delete;
+
+    vec3 m_lightDir{-1.0f, -2.0f, -0.5f}, m_La{0.0f, 0.0f, 0.0f}, m_Ld{1.0f, 1.0f, 1.0f};   // App.hpp:79-81
+    void ClearInstances() { m_world.clear(); m_world_it.clear(); }
+    // glm::translate(t) and transpose(inverse(.)) of it: the inverse of a translation is the opposite translation, exactly
+    void AddInstance(vec3 t) {
+        mat4 w = mat4::identity(), it = mat4::identity();
+        w.m[12] = t.x; w.m[13] = t.y; w.m[14] = t.z;
+        it.m[3] = -t.x; it.m[7] = -t.y; it.m[11] = -t.z;
+        m_world.push_back(w); m_world_it.push_back(it);
+    }
+    void AddInstance(const mat4 &world, const mat4 &world_inverse_transposed) { m_world.push_back(world); m_world_it.push_back(world_inverse_transposed); }
+
+    // depth_dev: the plane RayTracePass::Render wrote (gl_FragDepth); depth24_dev: width*height uint32_t of device memory that
+    // receives the attachment's 24-bit values and is then updated by the draws, like color_dev.
+    void Render(const mat4 &view_proj, uint32_t width, uint32_t height, float *color_dev, const float *depth_dev, uint32_t *depth24_dev, void *stream = nullptr) {
+        check(rt_depth_to_attachment(depth_dev, depth24_dev, (size_t)width * height, RT_MEM_DEVICE, stream));
+        rt_overlay_pass p{};
+        std::memcpy(p.view_proj, view_proj.m, sizeof p.view_proj);
+        std::memcpy(p.light_dir, &m_lightDir.x, 12); std::memcpy(p.la, &m_La.x, 12); std::memcpy(p.ld, &m_Ld.x, 12);
+        p.n_draws = (uint32_t)m_world.size();
+        p.world = m_world.empty() ? nullptr : m_world[0].m; p.world_it = m_world_it.empty() ? nullptr : m_world_it[0].m;
+        check(rt_overlay_draw(m_mesh, &p, color_dev, depth24_dev, width, height, RT_MEM_DEVICE, stream));
+    }
+private:
+    rt_overlay_mesh *m_mesh = nullptr;
+    std::vector<mat4> m_world, m_world_it;
 };
 
 // Camera.hpp:5-56.

@@ -23,7 +23,7 @@ def _soup(seed=5, n_tri=400):
     return pos, faces
 
 
-def _run_demo(tmp_path, pos, faces, render=None):
+def _run_demo(tmp_path, pos, faces, render=None, overlay=None):
     mesh_bin, out_bin = tmp_path / "mesh.bin", tmp_path / "out.bin"
     with open(mesh_bin, "wb") as f:
         f.write(np.array([len(pos), len(faces)], np.uint32).tobytes()); f.write(pos.tobytes()); f.write(faces.tobytes())
@@ -35,6 +35,11 @@ def _run_demo(tmp_path, pos, faces, render=None):
         us, w, h = render
         (tmp_path / "u.bin").write_bytes(np.concatenate(us).astype(np.float32).tobytes())
         cmd += [str(tmp_path / "u.bin"), str(w), str(h), str(len(us))]
+    if overlay:
+        ov, oi, ot = overlay
+        with open(tmp_path / "overlay.bin", "wb") as f:
+            f.write(np.array([len(ov), len(oi), ot.shape[1], ot.shape[0]], np.uint32).tobytes()); f.write(ov.tobytes()); f.write(oi.tobytes()); f.write(ot.tobytes())
+        cmd += [str(tmp_path / "overlay.bin")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     raw = out_bin.read_bytes()
@@ -51,6 +56,8 @@ def _run_demo(tmp_path, pos, faces, render=None):
         d["rgba"] = take(np.float32, w * h * 4).reshape(h, w, 4); d["depth"] = take(np.float32, w * h).reshape(h, w)
     if walk:
         d["uniforms"] = take(np.float32, render[3] * 70).reshape(-1, 70)
+    if overlay:
+        d["depth24"] = take(np.uint32, render[1] * render[2]).reshape(render[2], render[1])
     assert off == len(raw)
     return d
 
@@ -123,3 +130,48 @@ def test_cpp_camera_walk_like_the_reference_loop(tmp_path):
     assert np.array_equal(d["rgba"].view(np.uint32), acc.view(np.uint32))
     assert np.array_equal(d["depth"].view(np.uint32), depth.view(np.uint32))
     assert np.array_equal(d["rgba"].view(np.uint32), oacc.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_whole_frame_with_the_raster_pass(tmp_path):
+    """The demo's walk with rt::RasterPass after every ray-tracing draw (the whole of App::Render) against the Python mirror of the
+    same loop: accumulating rt_render, rt_depth_to_attachment, rt_overlay_draw with viewProj from the camera mirror."""
+    from raytracer_amd import glm_camera as g
+    pos, faces = _soup()
+    rng = np.random.default_rng(8)
+    n_t = 60                       # a small mesh in the default view: instance (0, -1) is not translated
+    ov = np.zeros((3 * n_t, 8), np.float32)
+    ov[:, :3] = (rng.uniform(0.2, 1.2, (n_t, 1, 3)) + rng.uniform(-0.3, 0.3, (n_t, 3, 3))).reshape(-1, 3)      # between the eye and the point it looks at
+    ov[:, 3:6] = rng.uniform(-1, 1, (3 * n_t, 3)); ov[:, 6:8] = rng.uniform(0, 1, (3 * n_t, 2))
+    oi = np.arange(3 * n_t, dtype=np.uint32)
+    ot = rng.integers(0, 256, (8, 16, 4), dtype=np.uint8)
+    w, h, n = 160, 96, 5
+    d = _run_demo(tmp_path, pos, faces, render=("walk", w, h, n), overlay=(ov, oi, ot))
+    cam = g.Camera(); cam.SetView((2, 2, 2), (0, 0, 0), (0, 1, 0)); cam.SetAspect(np.float32(w) / np.float32(h))
+    man = g.CameraManipulator(); man.SetCamera(cam)
+    p1, p2, pw, ph = g.default_portals()
+    man.KeyboardDown(g.KEY_W)
+    sc = api.Scene.from_octree(_python_octree(pos, faces))
+    mesh = api.OverlayMesh(ov, oi, ot)
+    worlds, its = [], []
+    for i in (-1, 0, 1):
+        for j in (-1, 0, 1):
+            t = np.array([4.0 * i, 4.0 + 4.0 * j, 0.0], np.float32)
+            wm = np.eye(4, dtype=np.float32); wm[3, :3] = t
+            it = np.eye(4, dtype=np.float32); it[:3, 3] = -t
+            worlds.append(wm.reshape(16)); its.append(it.reshape(16))
+    acc, counter = None, 1
+    for k in range(n):
+        if k + 2 == n:
+            man.KeyboardUp(g.KEY_W)
+        if man.Update(np.float32(1.0) / np.float32(60.0), p1, p2, pw, ph):
+            counter = 1
+        u = g.frame_uniforms(cam, p1, p2, pw, ph, time=np.float32(k) / np.float32(60.0))
+        r = sc.render(u, w, h, accum_index=counter, color=acc, planes=False)
+        counter += 1
+        acc = np.ascontiguousarray(r["rgba"], np.float32); d24 = api.depth_to_attachment(r["depth"])
+        mesh.draw(acc, d24, np.asarray(cam.GetViewProj(), np.float32).reshape(16), worlds, its, (-1.0, -2.0, -0.5), (0, 0, 0), (1, 1, 1))
+    sc.close(); mesh.close()
+    assert (d24 != api.depth_to_attachment(r["depth"])).sum() > 200          # the mesh is in view
+    assert np.array_equal(d["depth24"], d24)
+    assert np.array_equal(d["rgba"].view(np.uint32), acc.view(np.uint32))
