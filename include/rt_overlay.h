@@ -4,7 +4,8 @@
  * GL_DEPTH_TEST / GL_LEQUAL against the depth the ray tracer wrote through gl_FragDepth, blending disabled
  * (app/core/src/App.cpp:52-54,142-166).  The depth attachment is GL_DEPTH_COMPONENT24 (Framebuffer.cpp:10-12), so what
  * the rasterised fragments are tested against is a 24-bit value, not the float the shader wrote.  This header covers
- * the attachment value of a depth plane, the depth-tested merge of fragments produced by any rasteriser, and the pass itself:
+ * the attachment value of a depth plane, the depth-tested merge of fragments produced by any rasteriser, the 8-bit image the
+ * window receives, and the pass itself:
  * rt_overlay_draw rasterises an indexed mesh once per instance matrix with the reference's vertex and fragment stages
  * (Vert_PosNormTex.vert, Frag_LightingSimple.frag) into a colour plane and that 24-bit depth plane.
  */
@@ -69,6 +70,11 @@ typedef struct rt_overlay_pass {
  * calls, so calls on one mesh must not overlap. */
 int rt_overlay_draw(rt_overlay_mesh *mesh, const rt_overlay_pass *pass, float *color, uint32_t *depth24,
                     uint32_t width, uint32_t height, int memory, void *stream);
+
+/* What the window shows: Framebuffer::Blit (Framebuffer.cpp:33-35) copies the RGBA32F attachment onto the window's 8-bit
+ * framebuffer.  byte = round-to-nearest-even(float(clamp(c, 0, 1) * 255.0f)) per component, NaN -> 0 (pinned by read-backs of the
+ * window framebuffer on llvmpipe).  color: [n_pixels][4] floats; rgba8: [n_pixels][4] bytes.  memory / stream as above. */
+int rt_present_rgba8(const float *color, uint8_t *rgba8, size_t n_pixels, int memory, void *stream);
 
 #ifdef __cplusplus
 }

@@ -382,11 +382,42 @@ def overlay_fixtures():
                    frame_rgba=frame["rgba"], frame_depth24=depth24_of(frame["depth"]))
         if name == "through":      # three frames of App::Render: each ray-tracing draw blends over the FINISHED previous frame (mesh pixels included)
             times = (np.arange(3, dtype=np.float32) / np.float32(60.0)).astype(np.float32)
-            three = refrun.run_overlay(v, i, words, mtex, w, h, scene=scene, uniforms70=u, sky=sky, times=times)
-            out.update(times=times, three_rgba=three["rgba"], three_depth24=depth24_of(three["depth"]))
+            three = refrun.run_overlay(v, i, words, mtex, w, h, scene=scene, uniforms70=u, sky=sky, times=times, present=True)
+            out.update(times=times, three_rgba=three["rgba"], three_depth24=depth24_of(three["depth"]), three_present=three["present"])
         path = os.path.join(GOLDEN, f"ref_overlay_suzanne_{name}.npz")
         np.savez_compressed(path, **out)
         print("overlay", name, "mesh pixels alone", int((out["alone_depth24"] != 0xFFFFFF).sum()), "in the frame", int((out["frame_depth24"] != out["traced_depth24"]).sum()), os.path.getsize(path))
+
+
+PRESENT_FRAG = """#version 430
+layout(std430, binding = 0) buffer B { readonly vec4 xin[]; };
+out vec4 fs_out_col;
+void main() { uint i = uint(gl_FragCoord.y) * 64u + uint(gl_FragCoord.x); fs_out_col = xin[i]; }
+"""
+
+
+def present_fixture():
+    """ref_present.npz: 4096 colours (ramps beyond [0, 1], values around every tie k + 0.5, NaN and infinities; own probe text) and the
+    bytes the window's framebuffer holds after the blit of Framebuffer.cpp:33-35."""
+    import subprocess
+    import tempfile
+    rng = np.random.default_rng(0)
+    x = np.zeros((64 * 64, 4), np.float32)
+    x[:, 0] = np.linspace(-0.1, 1.1, 4096, dtype=np.float32)
+    x[:, 1] = (np.arange(4096) / 4096 * 255 + 0.5).astype(np.float32) / np.float32(255)
+    x[:, 2] = rng.uniform(0, 1, 4096).astype(np.float32)
+    x[:, 3] = rng.uniform(0, 1, 4096).astype(np.float32)
+    x[:8, 2] = [np.nan, np.inf, -np.inf, 0.5, 1.0, 0.0, -0.0, 1e-10]
+    x[100:356, 2] = ((np.arange(256) + 0.5) / 255).astype(np.float32)
+    with tempfile.TemporaryDirectory() as td:
+        pf = os.path.join(td, "p.frag"); open(pf, "w").write(PRESENT_FRAG)
+        pv = os.path.join(td, "p.vert")
+        open(pv, "w").write("#version 430\nout vec2 vs_out_ndc_coord;\nvoid main(){ vec2 p = vec2(gl_VertexID == 1 ? 3.0 : -1.0, gl_VertexID == 2 ? 3.0 : -1.0); gl_Position = vec4(p, 0.0, 1.0); vs_out_ndc_coord = p; }\n")
+        pi = os.path.join(td, "in"); x.tofile(pi)
+        subprocess.run([refrun.RUNNER, "--quiet", "--w", "64", "--h", "64", "--vert", pv, "--frag", pf, "--ssbo0", pi, "--noblend", "--present", "--out", os.path.join(td, "o")], check=True, capture_output=True)
+        p8 = np.fromfile(os.path.join(td, "o.present.u8"), np.uint8).reshape(-1, 4)
+    np.savez_compressed(os.path.join(GOLDEN, "ref_present.npz"), color=x, rgba8=p8)
+    print("present", os.path.getsize(os.path.join(GOLDEN, "ref_present.npz")))
 
 
 def accum8_fixture():
@@ -418,6 +449,7 @@ def main():
         refrun.build()
         assert refrun.available(), "needs /root/reference and the llvmpipe runner"
         overlay_fixtures()
+        present_fixture()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sky":
         refrun.build()

@@ -228,3 +228,9 @@ def octree_build(vertices, triangles, depth_limit=18, max_per_node=10, max_per_l
 def tri_box(center, halfsize, tri) -> bool:
     c = np.ascontiguousarray(center, np.float32); h = np.ascontiguousarray(halfsize, np.float32); t = np.ascontiguousarray(tri, np.float32).ravel()
     return bool(_olib().octree_oracle_tri_box(c.ctypes.data, h.ctypes.data, t.ctypes.data))
+
+
+def present_rgba8(color: np.ndarray) -> np.ndarray:
+    """The window's 8-bit image of an RGBA32F attachment (Framebuffer.cpp:33-35 on llvmpipe): rint(float32(clamp(c, 0, 1) * 255)), NaN -> 0."""
+    c = np.nan_to_num(np.clip(np.asarray(color, np.float32), 0, 1), nan=0.0).astype(np.float32)
+    return np.rint((c * np.float32(255.0)).astype(np.float32)).astype(np.uint8)

@@ -16,6 +16,8 @@
  * GL_LEQUAL against what the ray-tracing draw left in the depth attachment, one draw per instance matrix, a mip-mapped RGBA8
  * texture set up as GLUtils.cpp:193-224 does.  --no-rt skips the ray-tracing draw (colour 0, depth cleared to 1).
  *
+ * --present also performs the blit onto the window's framebuffer (Framebuffer.cpp:33-35) and dumps its 8-bit pixels.
+ *
  * No reference source text is contained in this file; the shader text never enters the repo.
  * The binary is written to oracle/_ref/ (git-ignored).  It only works where /root/reference
  * exists (this container), so it is used to generate the data fixtures under tests/golden/ and to
@@ -76,7 +78,7 @@ int main(int argc, char **argv) {
     const char *vert = "/root/reference/app/assets/ray_tracer.vert";
     const char *frag = "/root/reference/app/assets/ray_tracer.frag";
     const char *ssbo[4] = {0, 0, 0, 0}, *uniforms = 0, *bounds = 0, *sky = 0, *times = 0, *out = "refout";
-    int sky_w = 0, sky_h = 0, blend = 1, bench = 0, quiet = 0, no_rt = 0;
+    int sky_w = 0, sky_h = 0, blend = 1, bench = 0, quiet = 0, no_rt = 0, present = 0;
     const char *ov_vert = "/root/reference/app/assets/Vert_PosNormTex.vert", *ov_frag = "/root/reference/app/assets/Frag_LightingSimple.frag";
     const char *ov_vbo = 0, *ov_ibo = 0, *ov_uniforms = 0, *ov_tex = 0; int ov_tex_w = 0, ov_tex_h = 0;
     for (int i = 1; i < argc; i++) {
@@ -95,6 +97,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--overlay-tex")) { ov_tex = NEXT; ov_tex_w = atoi(NEXT); ov_tex_h = atoi(NEXT); }
         else if (!strcmp(a, "--overlay-vert")) ov_vert = NEXT; else if (!strcmp(a, "--overlay-frag")) ov_frag = NEXT;
         else if (!strcmp(a, "--no-rt")) no_rt = 1;
+        else if (!strcmp(a, "--present")) present = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
     void *glapi = dlopen("libglapi.so.0", RTLD_NOW | RTLD_GLOBAL);
@@ -305,6 +308,17 @@ int main(int argc, char **argv) {
     GLenum e = pglGetError(); if (e) { fprintf(stderr, "glGetError=0x%x\n", e); return 7; }
     dump(out, ".rgba.f32", px, sizeof(float) * 4 * (size_t)g_w * g_h);
     dump(out, ".depth.f32", dz, sizeof(float) * (size_t)g_w * g_h);
+    if (present) {      /* Framebuffer::Blit (Framebuffer.cpp:33-35): the colour attachment onto the window's 8-bit framebuffer */
+        GLF(PFNGLBLITNAMEDFRAMEBUFFERPROC, glBlitNamedFramebuffer);
+        glBlitNamedFramebuffer(fbo, 0, 0, 0, g_w, g_h, 0, 0, g_w, g_h, GL_COLOR_BUFFER_BIT, GL_LINEAR);
+        glBindFramebuffer(GL_FRAMEBUFFER, 0);
+        pglFinish();
+        uint8_t *p8 = malloc((size_t)g_w * g_h * 4);
+        pglReadPixels(0, 0, g_w, g_h, GL_RGBA, GL_UNSIGNED_BYTE, p8);
+        GLenum e2 = pglGetError(); if (e2) { fprintf(stderr, "present: glGetError=0x%x\n", e2); return 7; }
+        dump(out, ".present.u8", p8, (size_t)g_w * g_h * 4);
+        glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+    }
 
     if (bench > 0) {   /* steady-state timing of the last frame's state (CPU baseline numbers) */
         double best = 1e30, sum = 0;

@@ -155,7 +155,7 @@ def overlay_uniform_words(view_proj, worlds, world_its, light_dir, la, ld) -> np
 
 
 def run_overlay(vertices: np.ndarray, indices: np.ndarray, overlay_words: np.ndarray, texture: np.ndarray, width: int, height: int, *,
-                scene: dict | None = None, uniforms70=None, sky=None, times=None, frag_text: str | None = None, vert_text: str | None = None) -> dict:
+                scene: dict | None = None, uniforms70=None, sky=None, times=None, frag_text: str | None = None, vert_text: str | None = None, present: bool = False) -> dict:
     """The reference's raster pass (its own two shader files unless probe texts are given) on llvmpipe: `vertices` [n,8] f32
     (position, normal, texcoord), `indices` u32, `texture` [h,w,4] u8 (row 0 = bottom, as uploaded).  With `scene` the ray-tracing
     draw runs first, as in the reference's frame; without it the pass draws over colour 0 / depth 1.  Returns rgba [H,W,4], depth [H,W]."""
@@ -187,7 +187,12 @@ def run_overlay(vertices: np.ndarray, indices: np.ndarray, overlay_words: np.nda
                 args += ["--sky", w("s", sky), str(sky.shape[2]), str(sky.shape[1])]
             if times is not None:      # one whole frame (ray-tracing draw blended 1/(k+1), then the raster pass) per entry
                 args += ["--times", w("tm", np.asarray(times, np.float32))]
+        if present:
+            args += ["--present"]
         subprocess.run(args, check=True, capture_output=True, text=True)
         rgba = np.fromfile(os.path.join(td, "o.rgba.f32"), dtype=np.float32).reshape(height, width, 4)
         depth = np.fromfile(os.path.join(td, "o.depth.f32"), dtype=np.float32).reshape(height, width)
-    return {"rgba": rgba, "depth": depth}
+        out = {"rgba": rgba, "depth": depth}
+        if present:
+            out["present"] = np.fromfile(os.path.join(td, "o.present.u8"), dtype=np.uint8).reshape(height, width, 4)
+    return out

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "rt_manipulator_init", "rt_manipulator_set_camera", "rt_manipulator_update", "rt_manipulator_key", "rt_manipulator_mouse_move", "rt_manipulator_mouse_wheel",
     "rt_uniforms_set_camera", "rt_uniforms_set_portals",
     # include/rt_overlay.h
-    "rt_depth_to_attachment", "rt_overlay_composite", "rt_overlay_mesh_create", "rt_overlay_mesh_destroy", "rt_overlay_draw",
+    "rt_depth_to_attachment", "rt_overlay_composite", "rt_overlay_mesh_create", "rt_overlay_mesh_destroy", "rt_overlay_draw", "rt_present_rgba8",
     # include/rt_dist.h (bound in tests/test_gpu_dist_cabi.py)
     "rt_dist_make_id", "rt_dist_init", "rt_dist_rank", "rt_dist_world_size", "rt_dist_destroy", "rt_dist_scene_create", "rt_dist_skybox_set",
     "rt_dist_frame_bands", "rt_dist_gather_frame",
@@ -176,6 +176,28 @@ def depth_to_attachment(depth, out=None, stream: int | None = None):
     z = np.empty(d.shape, dtype=np.uint32) if out is None else out
     _check(L.rt_depth_to_attachment(d.ctypes.data, z.ctypes.data, d.size, RT_MEM_HOST, None))
     return z
+
+
+def present_rgba8(color, out=None, stream: int | None = None):
+    """rt_present_rgba8: the 8-bit image the window receives from the RGBA32F attachment (Framebuffer.cpp:33-35).  numpy [..., 4]
+    float32 in -> numpy uint8 out; GPU tensor in -> GPU uint8 tensor out."""
+    L = lib()
+    L.rt_present_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    if _is_tensor(color):
+        import torch
+        if color.dtype != torch.float32 or color.shape[-1] != 4:
+            raise ValueError("color: a float32 tensor [..., 4] is required")
+        if out is None:
+            out = torch.empty(color.shape, dtype=torch.uint8, device=color.device)
+        n = color.numel() // 4
+        p_in, mem, _k1 = _plane_ptr(color, None, 4 * n, "color")
+        p_out, _, _k2 = _plane_ptr(out, None, 4 * n, "out")
+        _check(L.rt_present_rgba8(p_in, p_out, n, mem, stream if stream is not None else torch.cuda.current_stream().cuda_stream))
+        return out
+    c = np.ascontiguousarray(color, dtype=np.float32)
+    o = np.empty(c.shape, dtype=np.uint8) if out is None else out
+    _check(L.rt_present_rgba8(c.ctypes.data, o.ctypes.data, c.size // 4, RT_MEM_HOST, None))
+    return o
 
 
 def overlay_composite(color, depth24, frag_color, frag_depth24, frag_mask=None, stream: int | None = None):

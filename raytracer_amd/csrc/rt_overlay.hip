@@ -1,5 +1,6 @@
-// The depth-attachment side of the reference's overlay pass (include/rt_overlay.h): two streaming kernels, bound by HBM
-// bandwidth (8 bytes per pixel for the conversion; 9 to 44 for the merge, depending on how many fragments pass).
+// The depth-attachment side of the reference's overlay pass and the presentation conversion (include/rt_overlay.h): three streaming
+// kernels, bound by HBM bandwidth (8 bytes per pixel for the depth conversion; 9 to 44 for the merge, depending on how many fragments
+// pass; 20 for the 8-bit image).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -46,6 +47,18 @@ __global__ __launch_bounds__(BLOCK) void overlay_composite_kernel(float4 *__rest
             color[i] = frag_color[i];
             depth24[i] = z;
         }
+    }
+}
+
+// Framebuffer.cpp:33-35: float colour -> the window's 8-bit unsigned normalised components.
+__device__ __forceinline__ uint32_t to_unorm8(float c) {
+    return (uint32_t)__builtin_rintf(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f);      // NaN becomes 0; the product is a float before the conversion
+}
+__global__ __launch_bounds__(BLOCK) void present_kernel(const float4 *__restrict__ color, uint32_t *__restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const float4 c = color[i];
+        out[i] = to_unorm8(c.x) | (to_unorm8(c.y) << 8) | (to_unorm8(c.z) << 16) | (to_unorm8(c.w) << 24);
     }
 }
 
@@ -138,5 +151,29 @@ extern "C" int rt_overlay_composite(float *color, uint32_t *depth24, const float
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipMemcpy(color, d_color, n * 16, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(depth24, d_z, n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_present_rgba8(const float *color, uint8_t *rgba8, size_t n, int memory, void *stream) {
+    if ((!color || !rgba8) && n) return rt_internal_set_error(RT_EINVAL, "rt_present_rgba8: null plane");
+    if (memory != RT_MEM_HOST && memory != RT_MEM_DEVICE) return rt_internal_set_error(RT_EINVAL, "rt_present_rgba8: memory must be RT_MEM_HOST or RT_MEM_DEVICE");
+    if (const int rc = device_ready()) return rc;
+    if (n == 0) return RT_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (memory == RT_MEM_DEVICE) {
+        if (((uintptr_t)color & 15u) || ((uintptr_t)rgba8 & 3u)) return rt_internal_set_error(RT_EINVAL, "rt_present_rgba8: the colour plane must be 16-byte aligned and the byte plane 4-byte aligned");
+        OnDeviceOf guard(rgba8);
+        present_kernel<<<grid_for(n), BLOCK, 0, st>>>(reinterpret_cast<const float4 *>(color), reinterpret_cast<uint32_t *>(rgba8), n);
+        HIP_OK(hipGetLastError());
+        return RT_OK;
+    }
+    Staged s;
+    void *d_in = nullptr, *d_out = nullptr;
+    HIP_OK(s.up(color, n * 16, &d_in));
+    HIP_OK(s.up(nullptr, n * 4, &d_out));
+    present_kernel<<<grid_for(n), BLOCK, 0, st>>>(static_cast<const float4 *>(d_in), static_cast<uint32_t *>(d_out), n);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemcpy(rgba8, d_out, n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }

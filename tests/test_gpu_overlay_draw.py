@@ -79,10 +79,17 @@ def test_three_frames_of_app_render(bunny_octree):
         rp.Render(u)
         api.depth_to_attachment(depth, out=d24)
         m.draw(col, d24, *split_words(z["words"]))
+    shown = api.present_rgba8(col)                      # Framebuffer::Blit: what the window receives
     torch.cuda.synchronize()
     assert np.array_equal(d24.cpu().numpy().view(np.uint32), z["three_depth24"])
     assert np.array_equal(bits(col.cpu().numpy()), bits(z["three_rgba"]))
+    assert np.array_equal(shown.cpu().numpy(), z["three_present"])
     m.close(); sc.close()
+
+
+def test_presented_bytes_of_probe_colours():
+    z = np.load(os.path.join(GOLDEN, "ref_present.npz"))
+    assert np.array_equal(api.present_rgba8(z["color"]), z["rgba8"])
 
 
 def test_4k_frame_on_device_equals_the_cpu_restatement():

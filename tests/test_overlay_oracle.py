@@ -61,6 +61,17 @@ def test_three_frames_of_the_whole_pass():
     assert np.array_equal(d24, z["three_depth24"]) and np.array_equal(bits(col), bits(z["three_rgba"]))
 
 
+def test_presented_bytes():
+    """Framebuffer::Blit onto the window's 8-bit framebuffer (Framebuffer.cpp:33-35): the probe colours and the third frame of the
+    whole Render() of the fixture above."""
+    from oracle import oracle
+    z = np.load(os.path.join(GOLDEN, "ref_present.npz"))
+    assert np.array_equal(oracle.present_rgba8(z["color"]), z["rgba8"])
+    t = np.load(os.path.join(GOLDEN, "ref_overlay_suzanne_through.npz"))
+    assert np.array_equal(oracle.present_rgba8(t["three_rgba"]), t["three_present"])
+    assert t["three_present"][..., 3].max() == 255 and t["three_present"][..., 3].min() == 0      # alpha: 1 on mesh pixels, 0 elsewhere (frag:670)
+
+
 def test_instance_matrices_and_light_of_the_reference():
     worlds, its = raster.reference_instances()
     assert len(worlds) == 9 and worlds[0][12:15].tolist() == [-4.0, 0.0, 0.0] and worlds[8][12:15].tolist() == [4.0, 8.0, 0.0]      # App.cpp:157-159
