@@ -62,10 +62,9 @@ typedef struct rt_overlay_pass {
  * reference sets it: back faces (clockwise in the window) culled, GL_LEQUAL depth test with depth writes, no blending, viewport =
  * the whole frame, depth range [0, 1].  Coverage, depth and colour are those of the reference's GL on llvmpipe bit for bit: vertex
  * stage, clipping against the six frustum planes, 1/256-pixel snapping with the left/bottom fill rule, plane equations and their
- * evaluation, the fragment stage and the 8-bit bilinear GL_REPEAT lookup (pinned by read-backs of that GL; the arithmetic is
- * stated in rt_raster.hip).  Limit: the texture is sampled from level 0 only; the reference asks for GL_LINEAR_MIPMAP_LINEAR
- * (GLUtils.cpp:219), which differs where a pixel covers more than one texel -- its own mesh carries a single constant texture
- * coordinate, where every lookup magnifies.  draws x triangles x 7 must stay below 2^32 (RT_ELIMIT).
+ * evaluation, the fragment stage and the texture lookup -- GL_LINEAR_MIPMAP_LINEAR / GL_LINEAR with GL_REPEAT on the mip chain
+ * glGenerateMipmap leaves (GLUtils.cpp:211-224), in that GL's 8-bit fixed point with its level of detail per 2 x 2 quad (pinned by
+ * read-backs of that GL; the arithmetic is stated in rt_raster.hip).  draws x triangles x 7 must stay below 2^32 (RT_ELIMIT).
  * memory / stream as above; the mesh keeps scratch buffers (8 bytes per pixel and 176 bytes per possible triangle) between
  * calls, so calls on one mesh must not overlap. */
 int rt_overlay_draw(rt_overlay_mesh *mesh, const rt_overlay_pass *pass, float *color, uint32_t *depth24,

@@ -339,10 +339,10 @@ def overlay_fixtures():
     tex = rng.integers(0, 256, (16, 8, 4), dtype=np.uint8)
     rec["texture"] = tex
     cam = Camera(eye=(0.3, 0.2, 1.0), at=(0, 0, 0), fovy=1.2, aspect=1.5, z_near=0.3, z_far=3.0)
-    for k in range(6):
+    for k in range(8):
         n = 40
         v = np.zeros((3 * n, 8), F)
-        spread, size = ((0.6, 0.39), (1.5, 1.2))[k >= 2]
+        spread, size = ((0.6, 0.39), (1.5, 1.2))[2 <= k < 6]
         c = rng.uniform(-spread, spread, (n, 1, 3)); v[:, :3] = (c + rng.uniform(-size, size, (n, 3, 3))).reshape(-1, 3)
         v[:, 3:6] = rng.uniform(-1, 1, (3 * n, 3))
         v[:, 6:8] = rng.uniform(0, 0.01, (3 * n, 2)) + rng.uniform(-2, 2, (n, 1, 2)).repeat(3, 1).reshape(-1, 2)
@@ -350,11 +350,14 @@ def overlay_fixtures():
             v[:, :2] = (rng.integers(0, 2 * 96 + 1, (3 * n, 2)) / F(96) - 1).astype(F) * np.array([1, 64 / 96], F)
         vp = cam.view_proj().ravel() if k % 2 else I
         words = raster.overlay_words(vp, [I], [I], (-1, -2, -0.5), (0.1, 0.2, 0.3), (0.9, 0.8, 0.7))
-        if k == 4:      # corners drawn from all over the soup: one texture coordinate for all, or the lookups would minify
+        if k >= 6:      # minified lookups: up to tens of texels per pixel, all mip levels, a texture whose sizes are not powers of two
+            v[:, 6:8] = rng.uniform(-1, 1, (3 * n, 2)) * (2.0, 14.0)[k - 6] + rng.uniform(-2, 2, (n, 1, 2)).repeat(3, 1).reshape(-1, 2)
+            rec[f"texture_{k}"] = rng.integers(0, 256, ((20, 12), (64, 32))[k - 6] + (4,), dtype=np.uint8)
+        if k == 4:      # corners drawn from all over the soup: one texture coordinate for all
             v[:, 6:8] = (0.37, -1.21)
         idx = rng.permutation(3 * n).astype(np.uint32) if k == 4 else np.arange(3 * n, dtype=np.uint32)
         idx = idx[: 3 * (len(idx) // 3)]
-        o = refrun.run_overlay(v, idx, words, tex, 96, 64)
+        o = refrun.run_overlay(v, idx, words, rec.get(f"texture_{k}", tex), 96, 64)
         rec[f"vertices_{k}"] = v; rec[f"indices_{k}"] = idx; rec[f"words_{k}"] = words
         rec[f"rgba_{k}"] = o["rgba"]; rec[f"depth24_{k}"] = depth24_of(o["depth"])
         print("soup", k, "covered", int((rec[f"depth24_{k}"] != 0xFFFFFF).sum()))

@@ -24,15 +24,15 @@
  *     nothing fused;
  *   - texture: per axis, a power-of-two size gives (c * size) * 256, any other size takes the fraction first, f = min(c - floor(c),
  *     0.99999994), and gives (f * size) * 256; rounded to nearest even, minus 128: texel = value >> 8 (wrapped), weight = value & 255;
- *     8-bit lerp(a, b, w) = a + (((b - a) * w + 128) >> 8) along x, then along y; result * (1 / 255).
+ *     8-bit lerp(a, b, w) = a + (((b - a) * w + 128) >> 8) along x, then along y (then between two mip levels); result * (1 / 255).
  *   - clipping: a triangle with a vertex outside any of the six planes -w <= x, y, z <= w is clipped plane by plane (x <= w, x >= -w,
  *     y <= w, y >= -w, z >= -w, z <= w; only the planes some vertex violates), walking the polygon from its first vertex; a new
  *     vertex on an edge is a + t * (b - a) for the clip position and every output, a being the end of the edge nearer to the
  *     plane (|d_a| < |d_b|, d = w -+ coordinate) whether it is inside or outside, t = d_a / (d_a - d_b), not fused, and its window position is ((clip * (1/w)) * scale) + translate, not fused either; the polygon (p0 .. pn-1) is
  *     drawn as the triangles (p[i-1], p[i], p0), each culled first by the sign of (v0 - v2) x (v1 - v2) in float window coordinates
  *     (the pieces of a clipped triangle only; negative = clockwise is dropped, zero passes on to the snapped-coordinate test).
- * Only level 0 of the texture is sampled (the reference's own mesh carries one constant texture coordinate, which
- * selects magnification); minified lookups are outside what this restatement pins.
+ *   - mip levels and their use: see build_mip_chain and sample_texture below (level of detail per 2 x 2 quad from the differences
+ *     of the texture coordinates at its lower left pixel, a log2 read off the float's bits, an 8-bit weight between two levels).
  */
 #include <math.h>
 #include <stdint.h>
@@ -67,9 +67,11 @@ static void to_window(out_vertex *o, int width, int height, int fused) {
     o->win[3] = oow;
 }
 
+#define MAX_LEVELS 16
+typedef struct { uint8_t *px; int w, h; } mip_level;
 typedef struct {
     int width, height;
-    const uint8_t *tex; int tex_w, tex_h;
+    mip_level level[MAX_LEVELS]; int n_levels;      /* level 0 = the texture as uploaded; the rest as glGenerateMipmap leaves them */
     float light[3], la[3], ld[3];
     float *color; uint32_t *depth24; uint32_t *tri_id;
 } target;
@@ -85,19 +87,73 @@ static int texel_fixed(float c, int size) {
     return (int)lrintf(f * (float)size * 256.0f);
 }
 
-static void sample_texture(const target *t, float u, float v, float out[4]) {
-    const int su = texel_fixed(u, t->tex_w) - 128, sv = texel_fixed(v, t->tex_h) - 128;
-    const int i0 = wrap(su >> 8, t->tex_w), i1 = wrap((su >> 8) + 1, t->tex_w), j0 = wrap(sv >> 8, t->tex_h), j1 = wrap((sv >> 8) + 1, t->tex_h);
+/* One bilinear lookup in 8-bit fixed point: lerp along x, then along y.  repeat: GL_REPEAT, else clamp to the edge texels. */
+static void bilinear8(const mip_level *l, float u, float v, int repeat, int out[4]) {
+    const int su = texel_fixed(u, l->w) - 128, sv = texel_fixed(v, l->h) - 128;
+    int i0 = su >> 8, i1 = (su >> 8) + 1, j0 = sv >> 8, j1 = (sv >> 8) + 1;
+    if (repeat) { i0 = wrap(i0, l->w); i1 = wrap(i1, l->w); j0 = wrap(j0, l->h); j1 = wrap(j1, l->h); }
+    else {
+        i0 = i0 < 0 ? 0 : i0 > l->w - 1 ? l->w - 1 : i0; i1 = i1 < 0 ? 0 : i1 > l->w - 1 ? l->w - 1 : i1;
+        j0 = j0 < 0 ? 0 : j0 > l->h - 1 ? l->h - 1 : j0; j1 = j1 < 0 ? 0 : j1 > l->h - 1 ? l->h - 1 : j1;
+    }
     const int wu = su & 255, wv = sv & 255;
     for (int c = 0; c < 4; c++) {
-        const int a = t->tex[((size_t)j0 * t->tex_w + i0) * 4 + c], b = t->tex[((size_t)j0 * t->tex_w + i1) * 4 + c];
-        const int d = t->tex[((size_t)j1 * t->tex_w + i0) * 4 + c], e = t->tex[((size_t)j1 * t->tex_w + i1) * 4 + c];
-        out[c] = (float)lerp8(lerp8(a, b, wu), lerp8(d, e, wu), wv) * (1.0f / 255.0f);
+        const int a = l->px[((size_t)j0 * l->w + i0) * 4 + c], b = l->px[((size_t)j0 * l->w + i1) * 4 + c];
+        const int d = l->px[((size_t)j1 * l->w + i0) * 4 + c], e = l->px[((size_t)j1 * l->w + i1) * 4 + c];
+        out[c] = lerp8(lerp8(a, b, wu), lerp8(d, e, wu), wv);
     }
 }
 
+/* glGenerateMipmap (GLUtils.cpp:215) as llvmpipe performs it: every texel of a level is ONE bilinear lookup of the level above at the
+ * texel's centre, edges clamped -- for even sizes the mean of four texels with the rounding of the 8-bit lerp, not a box filter's. */
+static int build_mip_chain(target *t, const uint8_t *texture, int w, int h) {
+    t->level[0].px = (uint8_t *)texture; t->level[0].w = w; t->level[0].h = h; t->n_levels = 1;
+    while ((w > 1 || h > 1) && t->n_levels < MAX_LEVELS) {
+        const mip_level *src = &t->level[t->n_levels - 1];
+        w = w > 1 ? w / 2 : 1; h = h > 1 ? h / 2 : 1;
+        mip_level *dst = &t->level[t->n_levels];
+        dst->w = w; dst->h = h; dst->px = malloc((size_t)w * h * 4);
+        if (!dst->px) return 1;
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                int c[4];
+                bilinear8(src, (float)((i + 0.5) / w), (float)((j + 0.5) / h), 0, c);
+                for (int k = 0; k < 4; k++) dst->px[((size_t)j * w + i) * 4 + k] = (uint8_t)c[k];
+            }
+        t->n_levels++;
+    }
+    return 0;
+}
+
+/* GL_LINEAR_MIPMAP_LINEAR / GL_LINEAR (GLUtils.cpp:217-219).  duv: the texture coordinates of the fragment's 2 x 2 quad -- [0] its
+ * lower left pixel (even x, even y), [1] the pixel to the right, [2] the pixel above -- which every fragment of the quad shares.
+ * rho^2 = max(|d(uv)/dx|^2, |d(uv)/dy|^2) in texels; lod = log2(rho^2) / 2 with log2 read off the float's bits (exponent + mantissa
+ * fraction: linear between powers of two); lod <= 0 magnifies (level 0); else levels floor(lod) and the next with the weight
+ * floor(fraction * 256) in the 8-bit lerp; beyond the last level, the last level. */
+static void sample_texture(const target *t, float u, float v, const float duv[3][2], float out[4]) {
+    const float tw = (float)t->level[0].w, th = (float)t->level[0].h;
+    const float a = (duv[1][0] - duv[0][0]) * tw, c = (duv[1][1] - duv[0][1]) * th, b = (duv[2][0] - duv[0][0]) * tw, d = (duv[2][1] - duv[0][1]) * th;
+    const float rho2 = fmaxf(a * a + c * c, b * b + d * d);
+    int32_t bits; memcpy(&bits, &rho2, 4);
+    const float lod = (float)(bits - 0x3f800000) * 0x1p-23f * 0.5f;
+    int col[4];
+    const int last = t->n_levels - 1;
+    if (!(lod > 0.0f)) bilinear8(&t->level[0], u, v, 1, col);
+    else {
+        const float fl = floorf(lod);
+        if (fl >= (float)last) bilinear8(&t->level[last], u, v, 1, col);
+        else {
+            const int l0 = (int)fl, w8 = (int)floorf((lod - fl) * 256.0f);
+            int c0[4], c1[4];
+            bilinear8(&t->level[l0], u, v, 1, c0); bilinear8(&t->level[l0 + 1], u, v, 1, c1);
+            for (int k = 0; k < 4; k++) col[k] = lerp8(c0[k], c1[k], w8);
+        }
+    }
+    for (int k = 0; k < 4; k++) out[k] = (float)col[k] * (1.0f / 255.0f);
+}
+
 /* Frag_LightingSimple.frag:29-41 */
-static void fragment_stage(const target *t, const float *a /* 8 varyings */, float out[4]) {
+static void fragment_stage(const target *t, const float *a /* 8 varyings */, const float duv[3][2], float out[4]) {
     const float nl = 1.0f / sqrtf((a[5] * a[5] + a[4] * a[4]) + a[3] * a[3]);
     const float n[3] = {a[3] * nl, a[4] * nl, a[5] * nl};
     const float m[3] = {-t->light[0], -t->light[1], -t->light[2]};
@@ -106,7 +162,7 @@ static void fragment_stage(const target *t, const float *a /* 8 varyings */, flo
     const float d = (n[2] * l[2] + n[1] * l[1]) + n[0] * l[0];
     const float cosa = fminf(fmaxf(d, 0.0f), 1.0f);
     float tx[4];
-    sample_texture(t, a[6], a[7], tx);
+    sample_texture(t, a[6], a[7], duv, tx);
     for (int c = 0; c < 3; c++) out[c] = (t->la[c] + cosa * t->ld[c]) * tx[c];
     out[3] = 1.0f * tx[3];
 }
@@ -163,9 +219,15 @@ static void raster_triangle(const target *t, const out_vertex *v0, const out_ver
             const size_t pi = (size_t)y * t->width + (size_t)x;
             if (!(d24 <= t->depth24[pi])) continue;
             const float w = 1.0f / fmaf(dady[1], yf, fmaf(dadx[1], xf, a0[1]));
-            float a[8], col[4];
+            float a[8], col[4], duv[3][2];
             for (int k = 0; k < 8; k++) a[k] = fmaf(dady[2 + k], yf, fmaf(dadx[2 + k], xf, a0[2 + k])) * w;
-            fragment_stage(t, a, col);
+            /* the texture coordinates at three pixels of the fragment's quad (covered or not: the planes extend beyond the triangle) */
+            for (int q = 0; q < 3; q++) {
+                const float qx = (float)((x & ~(int64_t)1) + (q == 1)), qy = (float)((y & ~(int64_t)1) + (q == 2));
+                const float qw = 1.0f / fmaf(dady[1], qy, fmaf(dadx[1], qx, a0[1]));
+                duv[q][0] = fmaf(dady[8], qy, fmaf(dadx[8], qx, a0[8])) * qw; duv[q][1] = fmaf(dady[9], qy, fmaf(dadx[9], qx, a0[9])) * qw;
+            }
+            fragment_stage(t, a, duv, col);
             memcpy(t->color + 4 * pi, col, sizeof col);
             t->depth24[pi] = d24;
             if (t->tri_id) t->tri_id[pi] = id;
@@ -212,7 +274,8 @@ static int clip_plane(const out_vertex *in, int n, int plane, out_vertex *out, i
 int raster_oracle_draw(const float *vertices, size_t n_vert, const uint32_t *indices, size_t n_idx, const float *words, size_t n_draws,
                        const uint8_t *texture, int tex_w, int tex_h, float *color, uint32_t *depth24, uint32_t *tri_id, int width, int height) {
     target t;
-    t.width = width; t.height = height; t.tex = texture; t.tex_w = tex_w; t.tex_h = tex_h;
+    t.width = width; t.height = height;
+    if (build_mip_chain(&t, texture, tex_w, tex_h)) return 2;
     memcpy(t.light, words + 16, 12); memcpy(t.la, words + 19, 12); memcpy(t.ld, words + 22, 12);
     t.color = color; t.depth24 = depth24; t.tri_id = tri_id;
     for (size_t i = 0; i < n_idx; i++) if (indices[i] >= n_vert) return 1;
@@ -251,5 +314,6 @@ int raster_oracle_draw(const float *vertices, size_t n_vert, const uint32_t *ind
         }
     }
     free(vs);
+    for (int l = 1; l < t.n_levels; l++) free(t.level[l].px);
     return 0;
 }

@@ -15,9 +15,11 @@
 // The key plane starts from the attachment's current values, so the test against what the ray tracer left is part of the merge.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <new>
+#include <vector>
 
 #include "../../include/rt_overlay.h"
 
@@ -44,10 +46,14 @@ struct RasterTri {
     uint32_t big, pad;                 // big: listed in the big-triangle list (the ordinary walk skips it)
 };
 
+constexpr int MAX_LEVELS = 16;
+struct MipTable { uint32_t n_levels; uint32_t w[MAX_LEVELS], h[MAX_LEVELS], offset[MAX_LEVELS]; };      // offsets in texels into one buffer
+
 struct PassConstants {
     float view_proj[16];
     float light[3], la[3], ld[3];
-    uint32_t n_draws, n_vert, n_tri, width, height, tex_w, tex_h;
+    uint32_t n_draws, n_vert, n_tri, width, height;
+    MipTable mip;
 };
 
 // mat4 * vec4 as the vertex stage evaluates it: ((c0*x + c1*y) + c2*z) + c3*w, nothing fused
@@ -286,19 +292,48 @@ __device__ __forceinline__ int texel_fixed(float c, int size) {
     return (int)__builtin_rintf(f * (float)size * 256.0f);
 }
 
-// GL_LINEAR with GL_REPEAT on level 0 of an RGBA8 texture, in the 8-bit fixed point of the reference's GL: the texel coordinate minus
-// 128 gives texel (>> 8) and weight (& 255); lerp(a, b, w) = a + (((b - a) * w + 128) >> 8) along x, then along y; the result times 1/255.
-__device__ void sample_texture(const uint8_t *__restrict__ tex, int tw, int th, float u, float v, float *out) {
+// One bilinear lookup with GL_REPEAT in the 8-bit fixed point of the reference's GL: the texel coordinate minus 128 gives texel (>> 8)
+// and weight (& 255); lerp(a, b, w) = a + (((b - a) * w + 128) >> 8) along x, then along y.
+__device__ void bilinear8(const uint8_t *__restrict__ tex, const MipTable &M, uint32_t level, float u, float v, int *out) {
+    const int tw = (int)M.w[level], th = (int)M.h[level];
+    const uchar4 *px = reinterpret_cast<const uchar4 *>(tex) + M.offset[level];
     const int su = texel_fixed(u, tw) - 128, sv = texel_fixed(v, th) - 128;
     const int i0 = wrap(su >> 8, tw), i1 = wrap((su >> 8) + 1, tw), j0 = wrap(sv >> 8, th), j1 = wrap((sv >> 8) + 1, th);
     const int wu = su & 255, wv = sv & 255;
-    const uchar4 a = reinterpret_cast<const uchar4 *>(tex)[(size_t)j0 * tw + i0], b = reinterpret_cast<const uchar4 *>(tex)[(size_t)j0 * tw + i1];
-    const uchar4 d = reinterpret_cast<const uchar4 *>(tex)[(size_t)j1 * tw + i0], e = reinterpret_cast<const uchar4 *>(tex)[(size_t)j1 * tw + i1];
-    const float k = 1.0f / 255.0f;
-    out[0] = (float)lerp8(lerp8(a.x, b.x, wu), lerp8(d.x, e.x, wu), wv) * k;
-    out[1] = (float)lerp8(lerp8(a.y, b.y, wu), lerp8(d.y, e.y, wu), wv) * k;
-    out[2] = (float)lerp8(lerp8(a.z, b.z, wu), lerp8(d.z, e.z, wu), wv) * k;
-    out[3] = (float)lerp8(lerp8(a.w, b.w, wu), lerp8(d.w, e.w, wu), wv) * k;
+    const uchar4 a = px[(size_t)j0 * tw + i0], b = px[(size_t)j0 * tw + i1], d = px[(size_t)j1 * tw + i0], e = px[(size_t)j1 * tw + i1];
+    out[0] = lerp8(lerp8(a.x, b.x, wu), lerp8(d.x, e.x, wu), wv);
+    out[1] = lerp8(lerp8(a.y, b.y, wu), lerp8(d.y, e.y, wu), wv);
+    out[2] = lerp8(lerp8(a.z, b.z, wu), lerp8(d.z, e.z, wu), wv);
+    out[3] = lerp8(lerp8(a.w, b.w, wu), lerp8(d.w, e.w, wu), wv);
+}
+
+// GL_LINEAR_MIPMAP_LINEAR / GL_LINEAR (GLUtils.cpp:217-219) as the reference's GL evaluates it.  uv0, uvx, uvy: the texture coordinates
+// at the lower left pixel of the fragment's 2 x 2 quad, at the pixel to its right and at the pixel above it (shared by the four
+// fragments of the quad).  rho^2 = max(|d(uv)/dx|^2, |d(uv)/dy|^2) in texels; lod = log2(rho^2) / 2 with the log2 read off the float's
+// bits (exponent + mantissa fraction: linear between powers of two); lod <= 0 magnifies (level 0); else levels floor(lod) and the next,
+// mixed by the 8-bit lerp with weight floor(fraction * 256); beyond the last level, the last level.  Result times 1/255.
+__device__ void sample_texture(const uint8_t *__restrict__ tex, const MipTable &M, float u, float v, float2 uv0, float2 uvx, float2 uvy, float *out) {
+    const float tw = (float)M.w[0], th = (float)M.h[0];
+    const float a = (uvx.x - uv0.x) * tw, c = (uvx.y - uv0.y) * th, b = (uvy.x - uv0.x) * tw, d = (uvy.y - uv0.y) * th;
+    const float rho2 = fmaxf(a * a + c * c, b * b + d * d);
+    const float lod = (float)(__float_as_int(rho2) - 0x3f800000) * 0x1p-23f * 0.5f;
+    int col[4];
+    const int last = (int)M.n_levels - 1;
+    if (!(lod > 0.0f)) bilinear8(tex, M, 0, u, v, col);
+    else {
+        const float fl = floorf(lod);
+        if (fl >= (float)last) bilinear8(tex, M, (uint32_t)last, u, v, col);
+        else {
+            const int l0 = (int)fl, w8 = (int)floorf((lod - fl) * 256.0f);
+            int c0[4], c1[4];
+            bilinear8(tex, M, (uint32_t)l0, u, v, c0); bilinear8(tex, M, (uint32_t)l0 + 1u, u, v, c1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) col[k] = lerp8(c0[k], c1[k], w8);
+        }
+    }
+    const float k255 = 1.0f / 255.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (float)col[k] * k255;
 }
 
 // Frag_LightingSimple.frag:29-41 with dot(a, b) = (a.z*b.z + a.y*b.y) + a.x*b.x, normalize(v) = v * (1 / sqrt(dot(v, v))),
@@ -322,8 +357,17 @@ __global__ __launch_bounds__(BLOCK) void resolve_kernel(PassConstants C, const R
         const float ml = 1.0f / sqrtf((mz * mz + my * my) + mx * mx);
         const float lx = mx * ml, ly = my * ml, lz = mz * ml;
         const float cosa = fminf(fmaxf((nz * lz + ny * ly) + nx * lx, 0.0f), 1.0f);
+        // the texture coordinates at three pixels of this fragment's quad (covered or not: the planes extend beyond the triangle)
+        const uint32_t px = (uint32_t)(i % C.width), py = (uint32_t)(i / C.width);
+        float2 quv[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const float qx = (float)((px & ~1u) + (q == 1 ? 1u : 0u)), qy = (float)((py & ~1u) + (q == 2 ? 1u : 0u));
+            const float qw = 1.0f / fmaf(T.dady[1], qy, fmaf(T.dadx[1], qx, T.a0[1]));
+            quv[q] = make_float2(fmaf(T.dady[8], qy, fmaf(T.dadx[8], qx, T.a0[8])) * qw, fmaf(T.dady[9], qy, fmaf(T.dadx[9], qx, T.a0[9])) * qw);
+        }
         float tx[4];
-        sample_texture(tex, (int)C.tex_w, (int)C.tex_h, a[6], a[7], tx);
+        sample_texture(tex, C.mip, a[6], a[7], quv[0], quv[1], quv[2], tx);
         color[i] = make_float4((C.la[0] + cosa * C.ld[0]) * tx[0], (C.la[1] + cosa * C.ld[1]) * tx[1], (C.la[2] + cosa * C.ld[2]) * tx[2], 1.0f * tx[3]);
         depth24[i] = (uint32_t)(key >> 32);
     }
@@ -345,12 +389,48 @@ struct Buffer {
 
 struct rt_overlay_mesh {
     int device = 0;
-    uint32_t n_vert = 0, n_tri = 0, tex_w = 0, tex_h = 0;
-    float *vertices = nullptr; uint32_t *indices = nullptr; uint8_t *texture = nullptr;
+    uint32_t n_vert = 0, n_tri = 0;
+    MipTable mip{};                                   // level 0 = the texture as given; the rest as glGenerateMipmap leaves them
+    float *vertices = nullptr; uint32_t *indices = nullptr; uint8_t *texture = nullptr;      // texture: all levels, one after the other
     Buffer out_vertices, slots, keys, matrices, big_list, stage_color, stage_depth;      // grown on demand, kept between calls
 };
 
 namespace {
+// Host side of GL_REPEAT-less lookups for the mip chain: the same fixed-point arithmetic as the device's, edges clamped.
+int host_lerp8(int a, int b, int w) { return a + (((b - a) * w + 128) >> 8); }
+int host_texel_fixed(float c, int size) {
+    if ((size & (size - 1)) == 0) return (int)std::lrintf(c * (float)size * 256.0f);
+    const float f = std::fmin(c - std::floor(c), 0.99999994f);
+    return (int)std::lrintf(f * (float)size * 256.0f);
+}
+// glGenerateMipmap (GLUtils.cpp:215) as the reference's GL performs it: every texel of a level is ONE bilinear lookup of the level
+// above at the texel's centre, edges clamped (for even sizes the mean of four texels with the rounding of the 8-bit lerp).
+void build_mip_chain(const uint8_t *texture, uint32_t w, uint32_t h, MipTable &M, std::vector<uint8_t> &out) {
+    out.assign(texture, texture + (size_t)w * h * 4);
+    M.n_levels = 1; M.w[0] = w; M.h[0] = h; M.offset[0] = 0;
+    while ((w > 1 || h > 1) && M.n_levels < (uint32_t)MAX_LEVELS) {
+        const uint32_t sw = w, sh = h, soff = M.offset[M.n_levels - 1];
+        w = w > 1 ? w / 2 : 1; h = h > 1 ? h / 2 : 1;
+        const uint32_t doff = (uint32_t)(out.size() / 4);
+        out.resize(out.size() + (size_t)w * h * 4);
+        const uint8_t *src = out.data() + (size_t)soff * 4;
+        uint8_t *dst = out.data() + (size_t)doff * 4;
+        for (uint32_t j = 0; j < h; j++)
+            for (uint32_t i = 0; i < w; i++) {
+                const int su = host_texel_fixed((float)((i + 0.5) / w), (int)sw) - 128, sv = host_texel_fixed((float)((j + 0.5) / h), (int)sh) - 128;
+                auto clampi = [](int a, int n) { return a < 0 ? 0 : a > n - 1 ? n - 1 : a; };
+                const int i0 = clampi(su >> 8, (int)sw), i1 = clampi((su >> 8) + 1, (int)sw), j0 = clampi(sv >> 8, (int)sh), j1 = clampi((sv >> 8) + 1, (int)sh);
+                const int wu = su & 255, wv = sv & 255;
+                for (int c = 0; c < 4; c++) {
+                    const int a = src[((size_t)j0 * sw + i0) * 4 + c], b = src[((size_t)j0 * sw + i1) * 4 + c], d = src[((size_t)j1 * sw + i0) * 4 + c], e = src[((size_t)j1 * sw + i1) * 4 + c];
+                    dst[((size_t)j * w + i) * 4 + c] = (uint8_t)host_lerp8(host_lerp8(a, b, wu), host_lerp8(d, e, wu), wv);
+                }
+            }
+        M.w[M.n_levels] = w; M.h[M.n_levels] = h; M.offset[M.n_levels] = doff;
+        M.n_levels++;
+    }
+}
+
 struct DeviceScope {
     int prev = -1; bool ok = false;
     explicit DeviceScope(int dev) { if (hipGetDevice(&prev) != hipSuccess) return; ok = prev == dev || hipSetDevice(dev) == hipSuccess; if (!ok) prev = -1; else if (prev == dev) prev = -1; }
@@ -374,8 +454,11 @@ extern "C" int rt_overlay_mesh_create(const float *vertices, size_t n_vert, cons
     if (!scope.ok) return rt_internal_set_error(RT_ENODEVICE, "rt_overlay_mesh_create: cannot select the HIP device");
     rt_overlay_mesh *m = new (std::nothrow) rt_overlay_mesh;
     if (!m) return rt_internal_set_error(RT_ENOMEM, "rt_overlay_mesh_create: out of host memory");
-    m->device = device; m->n_vert = (uint32_t)n_vert; m->n_tri = (uint32_t)(n_idx / 3); m->tex_w = tex_width; m->tex_h = tex_height;
-    const size_t tex_bytes = (size_t)tex_width * tex_height * 4;
+    m->device = device; m->n_vert = (uint32_t)n_vert; m->n_tri = (uint32_t)(n_idx / 3);
+    std::vector<uint8_t> levels;
+    build_mip_chain(texture_rgba, tex_width, tex_height, m->mip, levels);
+    texture_rgba = levels.data();
+    const size_t tex_bytes = levels.size();
     hipError_t e = hipMalloc(&m->vertices, n_vert * 32);
     if (e == hipSuccess) e = hipMalloc(&m->indices, n_idx * 4);
     if (e == hipSuccess) e = hipMalloc(&m->texture, tex_bytes);
@@ -437,7 +520,7 @@ extern "C" int rt_overlay_draw(rt_overlay_mesh *m, const rt_overlay_pass *pass, 
     PassConstants C;
     for (int k = 0; k < 16; k++) C.view_proj[k] = pass->view_proj[k];
     for (int k = 0; k < 3; k++) { C.light[k] = pass->light_dir[k]; C.la[k] = pass->la[k]; C.ld[k] = pass->ld[k]; }
-    C.n_draws = pass->n_draws; C.n_vert = m->n_vert; C.n_tri = m->n_tri; C.width = width; C.height = height; C.tex_w = m->tex_w; C.tex_h = m->tex_h;
+    C.n_draws = pass->n_draws; C.n_vert = m->n_vert; C.n_tri = m->n_tri; C.width = width; C.height = height; C.mip = m->mip;
     OutVertex *vs = static_cast<OutVertex *>(m->out_vertices.p);
     RasterTri *slots = static_cast<RasterTri *>(m->slots.p);
     unsigned long long *keys = static_cast<unsigned long long *>(m->keys.p);

@@ -26,11 +26,11 @@ def split_words(words):
     return words[:16], inst[:, :16], inst[:, 16:], words[16:19], words[19:22], words[22:25]
 
 
-@pytest.mark.parametrize("k", range(6))
+@pytest.mark.parametrize("k", range(8))
 def test_triangle_soups_match_llvmpipe(k):
     z = np.load(os.path.join(GOLDEN, "ref_overlay_soups.npz"))
     h, w = z[f"depth24_{k}"].shape
-    m = api.OverlayMesh(z[f"vertices_{k}"], z[f"indices_{k}"], z["texture"])
+    m = api.OverlayMesh(z[f"vertices_{k}"], z[f"indices_{k}"], z[f"texture_{k}"] if f"texture_{k}" in z.files else z["texture"])
     col = np.zeros((h, w, 4), np.float32); d24 = np.full((h, w), 0xFFFFFF, np.uint32)
     m.draw(col, d24, *split_words(z[f"words_{k}"]))
     m.close()
@@ -152,7 +152,7 @@ def test_random_soups_equal_the_cpu_restatement():
         if k % 5 == 0:
             v[2::3, :3] = v[1::3, :3] + rng.normal(0, 1e-3, (n, 3))
         v[:, 3:6] = rng.uniform(-1, 1, (3 * n, 3))
-        v[:, 6:8] = rng.uniform(-3, 3, (3 * n, 2)) if k % 3 else rng.uniform(-3, 3, 2)      # (level 0 on both sides, whatever the footprint)
+        v[:, 6:8] = rng.uniform(-3, 3, (3 * n, 2)) * float(10 ** rng.uniform(-2, 1)) if k % 3 else rng.uniform(-3, 3, 2)      # constant, magnified or minified
         th, tw = [(4, 4), (16, 8), (7, 5), (32, 32), (8, 5), (6, 16), (1, 1), (3, 64)][rng.integers(0, 8)]
         tex = rng.integers(0, 256, (th, tw, 4), dtype=np.uint8)
         if k % 2:

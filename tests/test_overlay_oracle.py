@@ -16,16 +16,17 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("k", range(6))
+@pytest.mark.parametrize("k", range(8))
 def test_triangle_soups_bit_exact(k):
-    """Clipped by every frustum plane (k >= 2), perspective (odd k), shuffled draw order (4), edges through pixel centres (5)."""
+    """Clipped by every frustum plane (2-5), perspective (odd k), shuffled draw order (4), edges through pixel centres (5), minified
+    lookups through all mip levels (6, 7)."""
     z = np.load(os.path.join(GOLDEN, "ref_overlay_soups.npz"))
     h, w = z[f"depth24_{k}"].shape
     col = np.zeros((h, w, 4), np.float32); d24 = np.full((h, w), 0xFFFFFF, np.uint32)
-    raster.draw(z[f"vertices_{k}"], z[f"indices_{k}"], z[f"words_{k}"], z["texture"], col, d24)
+    raster.draw(z[f"vertices_{k}"], z[f"indices_{k}"], z[f"words_{k}"], z[f"texture_{k}"] if f"texture_{k}" in z.files else z["texture"], col, d24)
     assert np.array_equal(d24, z[f"depth24_{k}"])
     assert np.array_equal(bits(col), bits(z[f"rgba_{k}"]))
-    assert (d24 != 0xFFFFFF).sum() > 1000
+    assert (d24 != 0xFFFFFF).sum() > 500
 
 
 @pytest.mark.parametrize("path", SUZANNE_FILES, ids=[os.path.basename(p)[20:-4] for p in SUZANNE_FILES])
