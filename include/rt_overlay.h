@@ -75,6 +75,16 @@ int rt_overlay_draw(rt_overlay_mesh *mesh, const rt_overlay_pass *pass, float *c
  * window framebuffer on llvmpipe).  color: [n_pixels][4] floats; rgba8: [n_pixels][4] bytes.  memory / stream as above. */
 int rt_present_rgba8(const float *color, uint8_t *rgba8, size_t n_pixels, int memory, void *stream);
 
+/* rt_overlay_draw for one owner's rows of the frame, with rt_frame's rule (rt_hotpath.h): strips of band_rows rows are dealt out to
+ * band_parts owners and this call draws the strips of band_part; with compact_rows the two planes hold only those rows
+ * (rt_band_row_count() of them), else the whole frame, of which the other rows are left alone.  The fragments are those of the
+ * whole-frame call: the union of the owners' results equals rt_overlay_draw's.  No counterpart in the reference (one GPU draws its
+ * whole frame); it keeps the frame exact when several GPUs each accumulate their rows, since the reference's next ray-tracing draw
+ * blends over the finished frame, rasterised pixels included. */
+int rt_overlay_draw_band(rt_overlay_mesh *mesh, const rt_overlay_pass *pass, float *color, uint32_t *depth24,
+                         uint32_t width, uint32_t height, uint32_t band_rows, uint32_t band_parts, uint32_t band_part,
+                         uint32_t compact_rows, int memory, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

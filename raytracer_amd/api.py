@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "rt_manipulator_init", "rt_manipulator_set_camera", "rt_manipulator_update", "rt_manipulator_key", "rt_manipulator_mouse_move", "rt_manipulator_mouse_wheel",
     "rt_uniforms_set_camera", "rt_uniforms_set_portals",
     # include/rt_overlay.h
-    "rt_depth_to_attachment", "rt_overlay_composite", "rt_overlay_mesh_create", "rt_overlay_mesh_destroy", "rt_overlay_draw", "rt_present_rgba8",
+    "rt_depth_to_attachment", "rt_overlay_composite", "rt_overlay_mesh_create", "rt_overlay_mesh_destroy", "rt_overlay_draw", "rt_overlay_draw_band", "rt_present_rgba8",
     # include/rt_dist.h (bound in tests/test_gpu_dist_cabi.py)
     "rt_dist_make_id", "rt_dist_init", "rt_dist_rank", "rt_dist_world_size", "rt_dist_destroy", "rt_dist_scene_create", "rt_dist_skybox_set",
     "rt_dist_frame_bands", "rt_dist_gather_frame",
@@ -240,16 +240,18 @@ class OverlayMesh:
         L.rt_overlay_mesh_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_overlay_mesh_destroy.argtypes = [C.c_void_p]
         L.rt_overlay_draw.argtypes = [C.c_void_p, C.POINTER(rt_overlay_pass), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.rt_overlay_draw_band.argtypes = [C.c_void_p, C.POINTER(rt_overlay_pass), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         v = np.ascontiguousarray(vertices, np.float32); i = np.ascontiguousarray(indices, np.uint32).reshape(-1); t = np.ascontiguousarray(texture, np.uint8)
         if v.ndim != 2 or v.shape[1] != 8 or t.ndim != 3 or t.shape[2] != 4:
             raise ValueError("vertices must be [n, 8] and the texture [h, w, 4]")
         self._h = C.c_void_p()
         _check(L.rt_overlay_mesh_create(v.ctypes.data, len(v), i.ctypes.data, len(i), t.ctypes.data, t.shape[1], t.shape[0], device, C.byref(self._h)))
 
-    def draw(self, color, depth24, view_proj, worlds, world_its, light_dir, la, ld, stream: int | None = None):
+    def draw(self, color, depth24, view_proj, worlds, world_its, light_dir, la, ld, stream: int | None = None, band=None, frame_height: int | None = None):
         """rt_overlay_draw: the draws of App.cpp:147-164 over `color` ([h, w, 4] float32) and `depth24` ([h, w], 24-bit values), in
         place.  Both numpy arrays (C-contiguous float32 / uint32) or both contiguous GPU tensors (depth24 int32 holding the values).
-        Matrices are column-major sequences of 16 floats."""
+        Matrices are column-major sequences of 16 floats.  band = (band_rows, band_parts, band_part, compact): rt_overlay_draw_band on one
+        owner's rows; with compact the planes hold only those rows and frame_height gives the frame's."""
         tensors = _is_tensor(color)
         if tensors:
             import torch
@@ -271,7 +273,10 @@ class OverlayMesh:
         p.view_proj[:] = [float(x) for x in np.asarray(view_proj, np.float32).reshape(16)]
         p.light_dir[:] = [float(x) for x in np.asarray(light_dir, np.float32)]; p.la[:] = [float(x) for x in np.asarray(la, np.float32)]; p.ld[:] = [float(x) for x in np.asarray(ld, np.float32)]
         p.n_draws = len(wm); p.world = wm.ctypes.data; p.world_it = wi.ctypes.data
-        _check(lib().rt_overlay_draw(self._h, C.byref(p), pc, pz, w, h, mem, stream))
+        if band is None:
+            _check(lib().rt_overlay_draw(self._h, C.byref(p), pc, pz, w, h, mem, stream))
+        else:
+            _check(lib().rt_overlay_draw_band(self._h, C.byref(p), pc, pz, w, frame_height if frame_height is not None else h, band[0], band[1], band[2], int(bool(band[3])), mem, stream))
         return color, depth24
 
     def close(self):

@@ -53,8 +53,14 @@ struct PassConstants {
     float view_proj[16];
     float light[3], la[3], ld[3];
     uint32_t n_draws, n_vert, n_tri, width, height;
+    uint32_t band_rows, band_parts, band_part, compact, plane_rows;      // which rows of the frame this call draws, and how the planes hold them
     MipTable mip;
 };
+
+// Rows of the frame are dealt out in strips of band_rows to band_parts owners (rt_frame's rule); a compact plane holds only its owner's strips.
+__device__ __forceinline__ bool row_in_band(const PassConstants &C, uint32_t y) { return (y / C.band_rows) % C.band_parts == C.band_part; }
+__device__ __forceinline__ uint32_t plane_row_of(const PassConstants &C, uint32_t y) { return C.compact ? (y / C.band_rows / C.band_parts) * C.band_rows + y % C.band_rows : y; }
+__device__ __forceinline__ uint32_t frame_row_of(const PassConstants &C, uint32_t row) { return C.compact ? ((row / C.band_rows) * C.band_parts + C.band_part) * C.band_rows + row % C.band_rows : row; }
 
 // mat4 * vec4 as the vertex stage evaluates it: ((c0*x + c1*y) + c2*z) + c3*w, nothing fused
 __device__ __forceinline__ void mat_vec(const float *M, float x, float y, float z, float w, float *out) {
@@ -252,7 +258,7 @@ __device__ void cover_tiles(const PassConstants &C, const RasterTri &T, uint32_t
         }
         if (tile_out) continue;
         const int32_t x = x0 + lx, y = y0 + ly;
-        bool inside = x <= x_hi && y <= y_hi;
+        bool inside = x <= x_hi && y <= y_hi && row_in_band(C, (uint32_t)y);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int64_t e = base[k] + lane_part[k];
@@ -261,7 +267,7 @@ __device__ void cover_tiles(const PassConstants &C, const RasterTri &T, uint32_t
         if (!inside) continue;
         const float z = fmaf(dady, (float)y, fmaf(dadx, (float)x, a0));
         const unsigned long long key = ((unsigned long long)to_depth24(z) << 32) | order;
-        unsigned long long *p = keys + (size_t)y * C.width + (size_t)x;
+        unsigned long long *p = keys + (size_t)plane_row_of(C, (uint32_t)y) * C.width + (size_t)x;
         if (key < *p) atomicMin(p, key);
     }
 }
@@ -340,13 +346,14 @@ __device__ void sample_texture(const uint8_t *__restrict__ tex, const MipTable &
 // clamp = min(max(., 0), 1); a varying is fma(dady, y, fma(dadx, x, a0)) * (1 / (1/w interpolated the same way)).
 __global__ __launch_bounds__(BLOCK) void resolve_kernel(PassConstants C, const RasterTri *__restrict__ slots, const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ tex,
                                                         float4 *__restrict__ color, uint32_t *__restrict__ depth24) {
-    const size_t n = (size_t)C.width * C.height, stride = (size_t)gridDim.x * BLOCK;
+    const size_t n = (size_t)C.width * C.plane_rows, stride = (size_t)gridDim.x * BLOCK;
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const unsigned long long key = keys[i];
         const uint32_t low = (uint32_t)key;
         if (low == NO_FRAGMENT) continue;
         const RasterTri &T = slots[NO_FRAGMENT - 1u - low];
-        const float xf = (float)(i % C.width), yf = (float)(i / C.width);
+        const uint32_t px = (uint32_t)(i % C.width), py = frame_row_of(C, (uint32_t)(i / C.width));
+        const float xf = (float)px, yf = (float)py;
         const float w = 1.0f / fmaf(T.dady[1], yf, fmaf(T.dadx[1], xf, T.a0[1]));
         float a[8];
 #pragma unroll
@@ -358,7 +365,6 @@ __global__ __launch_bounds__(BLOCK) void resolve_kernel(PassConstants C, const R
         const float lx = mx * ml, ly = my * ml, lz = mz * ml;
         const float cosa = fminf(fmaxf((nz * lz + ny * ly) + nx * lx, 0.0f), 1.0f);
         // the texture coordinates at three pixels of this fragment's quad (covered or not: the planes extend beyond the triangle)
-        const uint32_t px = (uint32_t)(i % C.width), py = (uint32_t)(i / C.width);
         float2 quv[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -487,7 +493,13 @@ extern "C" int rt_overlay_mesh_destroy(rt_overlay_mesh *m) {
 }
 
 extern "C" int rt_overlay_draw(rt_overlay_mesh *m, const rt_overlay_pass *pass, float *color, uint32_t *depth24, uint32_t width, uint32_t height, int memory, void *stream) {
+    return rt_overlay_draw_band(m, pass, color, depth24, width, height, 16, 1, 0, 0, memory, stream);
+}
+
+extern "C" int rt_overlay_draw_band(rt_overlay_mesh *m, const rt_overlay_pass *pass, float *color, uint32_t *depth24, uint32_t width, uint32_t height,
+                                    uint32_t band_rows, uint32_t band_parts, uint32_t band_part, uint32_t compact_rows, int memory, void *stream) {
     if (!m || !pass) return rt_internal_set_error(RT_EINVAL, "rt_overlay_draw: mesh or pass is null");
+    if (band_rows == 0 || band_parts == 0 || band_part >= band_parts) return rt_internal_set_error(RT_EINVAL, "rt_overlay_draw_band: band_rows and band_parts must be positive and band_part below band_parts");
     if (!color || !depth24) return rt_internal_set_error(RT_EINVAL, "rt_overlay_draw: null plane");
     if (memory != RT_MEM_HOST && memory != RT_MEM_DEVICE) return rt_internal_set_error(RT_EINVAL, "rt_overlay_draw: memory must be RT_MEM_HOST or RT_MEM_DEVICE");
     if (width == 0 || height == 0 || width > 32768 || height > 32768) return rt_internal_set_error(RT_EINVAL, "rt_overlay_draw: frame size must be in [1, 32768]");
@@ -499,7 +511,14 @@ extern "C" int rt_overlay_draw(rt_overlay_mesh *m, const rt_overlay_pass *pass, 
     DeviceScope scope(m->device);
     if (!scope.ok) return rt_internal_set_error(RT_ENODEVICE, "rt_overlay_draw: cannot select the mesh's HIP device");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t n_px = (size_t)width * height;
+    uint32_t plane_rows = height;
+    if (compact_rows) {      // the rows of this owner's strips (the last strip of the frame may be short)
+        const uint32_t strips = (height + band_rows - 1) / band_rows;
+        plane_rows = 0;
+        for (uint32_t sidx = band_part; sidx < strips; sidx += band_parts) plane_rows += sidx + 1 == strips ? height - sidx * band_rows : band_rows;
+        if (plane_rows == 0) return RT_OK;
+    }
+    const size_t n_px = (size_t)width * plane_rows;
     // scratch of an earlier call may still be in use by work enqueued on another stream
     const size_t want_v = (size_t)pass->n_draws * m->n_vert * sizeof(OutVertex), want_s = (size_t)n_slots * sizeof(RasterTri), want_k = n_px * 8, want_m = (size_t)pass->n_draws * 32 * 4;
     const size_t want_b = (size_t)(1u + (n_slots < BIG_CAPACITY ? (uint32_t)n_slots : BIG_CAPACITY)) * 4;
@@ -521,6 +540,7 @@ extern "C" int rt_overlay_draw(rt_overlay_mesh *m, const rt_overlay_pass *pass, 
     for (int k = 0; k < 16; k++) C.view_proj[k] = pass->view_proj[k];
     for (int k = 0; k < 3; k++) { C.light[k] = pass->light_dir[k]; C.la[k] = pass->la[k]; C.ld[k] = pass->ld[k]; }
     C.n_draws = pass->n_draws; C.n_vert = m->n_vert; C.n_tri = m->n_tri; C.width = width; C.height = height; C.mip = m->mip;
+    C.band_rows = band_rows; C.band_parts = band_parts; C.band_part = band_part; C.compact = compact_rows ? 1u : 0u; C.plane_rows = plane_rows;
     OutVertex *vs = static_cast<OutVertex *>(m->out_vertices.p);
     RasterTri *slots = static_cast<RasterTri *>(m->slots.p);
     unsigned long long *keys = static_cast<unsigned long long *>(m->keys.p);

@@ -175,3 +175,36 @@ def test_random_soups_equal_the_cpu_restatement():
         m.close()
         assert np.array_equal(d24, want_d), k
         assert np.array_equal(bits(col), bits(want_c)), k
+
+
+@pytest.mark.parametrize("band_rows,parts", [(16, 2), (5, 3), (16, 8)])
+def test_band_draws_reassemble_the_frame(band_rows, parts):
+    """rt_overlay_draw_band: every owner draws its strips (full-frame planes left alone elsewhere, or compact planes of its rows only);
+    together they give the whole-frame draw bit for bit, mip-mapped lookups (quads span two rows) included."""
+    a = np.load(os.path.join(GOLDEN, "overlay_assets.npz"))
+    from raytracer_amd.camera import Camera
+    w, h = 200, 150
+    rng = np.random.default_rng(band_rows * 10 + parts)
+    v = a["vertices"].copy(); v[:, 6:8] = rng.uniform(-4, 4, (len(v), 2))      # give the mesh texture coordinates: minified lookups
+    tex = rng.integers(0, 256, (24, 40, 4), dtype=np.uint8)
+    cam = Camera(eye=(-2.5, 5.25, 9.0), at=(-2.5, 5.25, 4.1), aspect=w / h)
+    worlds, its = raster.reference_instances()
+    args = (cam.view_proj().ravel(), worlds, its, (-1.0, -2.0, -0.5), (0.1, 0.1, 0.1), (1.0, 1.0, 1.0))
+    col0 = rng.random((h, w, 4), dtype=np.float32); d0 = rng.integers(0xFF9800, 0x1000000, (h, w), dtype=np.uint32)
+    m = api.OverlayMesh(v, a["indices"], tex)
+    want_c, want_d = col0.copy(), d0.copy()
+    m.draw(want_c, want_d, *args)
+    assert (want_d != d0).sum() > 2000
+    full_c, full_d = col0.copy(), d0.copy()
+    comp_c, comp_d = col0.copy(), d0.copy()
+    for part in range(parts):
+        m.draw(full_c, full_d, *args, band=(band_rows, parts, part, False))
+        rows = np.array([y for y in range(h) if (y // band_rows) % parts == part])
+        if len(rows) == 0:
+            continue
+        pc, pd = np.ascontiguousarray(col0[rows]), np.ascontiguousarray(d0[rows])
+        m.draw(pc, pd, *args, band=(band_rows, parts, part, True), frame_height=h)
+        comp_c[rows], comp_d[rows] = pc, pd
+    m.close()
+    assert np.array_equal(full_d, want_d) and np.array_equal(bits(full_c), bits(want_c))
+    assert np.array_equal(comp_d, want_d) and np.array_equal(bits(comp_c), bits(want_c))
