@@ -13,7 +13,7 @@ from raytracer_amd import api
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_accum8.npz", "ref_math.npz", "ref_sky_sizes.npz") and not os.path.basename(f).startswith(("ref_ndc_", "ref_overlay_")))
+VIEW_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if os.path.basename(f) not in ("ref_accum.npz", "ref_accum8.npz", "ref_math.npz", "ref_sky_sizes.npz", "ref_present.npz") and not os.path.basename(f).startswith(("ref_ndc_", "ref_overlay_")))
 
 
 def bits(a):
