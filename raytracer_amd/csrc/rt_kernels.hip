@@ -623,19 +623,23 @@ DEVI bool hits_risky(const RtDeviceScene &S, const Ray &r) {
     for (uint32_t k = 0; k < S.n_risky; k++) hit = hit || ray_triangle(r, load_triangle(S.risky_tris + k)) >= 0.0f;
     return hit;
 }
-template <bool EXACT>
+// EXACT: 0 = plain traversal; 1 = exact near-first for segments whose slot nobody observes (ties between different triangles only);
+// 2 = the same with the rank bookkeeping that step 2 needs.  (Kept apart because the bookkeeping is not free: on the 1.28 M-triangle
+// frame the tie flag costs 0.85 ms of 17.4 and the ranks another 0.6.)
+template <int EXACT>
 DEVI void accept_hit(float t, uint32_t slot, uint32_t id, uint32_t node_rank, float &closest, uint32_t &closest_tri, bool &tri_hit, Exact &x) {
     if (t >= 0.0f && t < closest) {
         closest = t; closest_tri = slot; tri_hit = true;
-        if (EXACT) { x.best_rank = node_rank; x.best_id = id; x.tie = false; }
+        if (EXACT) { x.best_id = id; x.tie = false; }
+        if (EXACT == 2) x.best_rank = node_rank;
     } else if (EXACT && x.nf && tri_hit && t == closest) {
         if (id != x.best_id) x.tie = true;
-        else if (node_rank < x.best_rank || (node_rank == x.best_rank && slot < closest_tri)) { closest_tri = slot; x.best_rank = node_rank; }
+        else if (EXACT == 2 && (node_rank < x.best_rank || (node_rank == x.best_rank && slot < closest_tri))) { closest_tri = slot; x.best_rank = node_rank; }
     }
 }
 // Must be called by all lanes of a wave together; `active` marks the lanes with a live traversal and is cleared when a
 // lane's traversal is complete.  mode: RtLaunch::near_first (0: the reference's order, 1: near first, 2: exact near first).
-template <bool COUNT, bool EXACT, class STACK>
+template <bool COUNT, int EXACT, class STACK>
 DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, STACK &st, Walk &w, Exact &x, bool near_first, float &closest, uint32_t &closest_tri, bool &tri_hit, bool &active, Counters &cn) {
     const bool want_tri = active && w.tri_i < w.tri_end;
     const uint32_t n_tri = (uint32_t)__popcll(__ballot(want_tri)), n_pop = (uint32_t)__popcll(__ballot(active && !want_tri));
@@ -651,7 +655,7 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
             w.tri_i = min(w.tri_i + TRI_BATCH, w.tri_end);
         }
     } else if (active && !want_tri) {
-        if (EXACT && x.post_q < x.post_end) {
+        if (EXACT == 2 && x.post_q < x.post_end) {
             // step 2, one candidate per step: the box of the node that holds a reference of the hit triangle, derived from its
             // parent's record.  For the kept reference itself (the last position) the question is whether its node is entered
             // no later than the hit (tmin <= t*: then R visits it); for an earlier reference, whether the ray passes through
@@ -692,7 +696,7 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
         if (st.empty()) {
             if (nf_pass && tri_hit) {
                 const bool redo = x.tie;
-                if (!redo && x.slot) {
+                if (!redo && EXACT == 2 && x.slot) {
                     x.post_q = S.tris[closest_tri].dup_first; x.post_end = S.tris[closest_tri].dup_pos + 1u;   // (at least the kept reference itself)
                     return;
                 }
@@ -1419,7 +1423,7 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
     }
 }
 
-template <int LEVELS, bool COUNT, bool EXACT>
+template <int LEVELS, bool COUNT, int EXACT>
 __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
     __shared__ TopLevels lds_top;
@@ -1734,7 +1738,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                 const unsigned long long w = __ballot(!traversing && (has_path || unit < n_units));
                 if ((uint32_t)__popcll(w) >= (unit < n_units ? PATH_REFILL : 1u)) break;
             }
-            walk_step<COUNT, EXACT>(S, &lds_top, ray, st, walk, x, L.near_first != 0u, closest, closest_tri, tri_hit, traversing, cn);
+            walk_step<COUNT, EXACT ? 2 : 0>(S, &lds_top, ray, st, walk, x, L.near_first != 0u, closest, closest_tri, tri_hit, traversing, cn);
         }
     }
 #ifdef PATH_TRACE   // development aid: per-wave start / end wall clock behind the counters
@@ -1774,12 +1778,15 @@ int launch_megakernel(const RtDeviceScene &S, const RtLaunch &L, hipStream_t st,
 
 template <int LEVELS>
 void launch_traverse(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace &WS, uint32_t d, hipStream_t st, dim3 grid) {
-    if (L.near_first == 2u) {
-        if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true, true>), grid, dim3(256), 0, st, S, L, WS, d);
-        else hipLaunchKernelGGL((traverse_kernel<LEVELS, false, true>), grid, dim3(256), 0, st, S, L, WS, d);
+    if (L.near_first == 2u && d == 0u && L.hit_slot != nullptr) {      // the primary hit's slot goes to the caller's plane
+        if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true, 2>), grid, dim3(256), 0, st, S, L, WS, d);
+        else hipLaunchKernelGGL((traverse_kernel<LEVELS, false, 2>), grid, dim3(256), 0, st, S, L, WS, d);
+    } else if (L.near_first == 2u) {
+        if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true, 1>), grid, dim3(256), 0, st, S, L, WS, d);
+        else hipLaunchKernelGGL((traverse_kernel<LEVELS, false, 1>), grid, dim3(256), 0, st, S, L, WS, d);
     } else {
-        if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true, false>), grid, dim3(256), 0, st, S, L, WS, d);
-        else hipLaunchKernelGGL((traverse_kernel<LEVELS, false, false>), grid, dim3(256), 0, st, S, L, WS, d);
+        if (L.counters) hipLaunchKernelGGL((traverse_kernel<LEVELS, true, 0>), grid, dim3(256), 0, st, S, L, WS, d);
+        else hipLaunchKernelGGL((traverse_kernel<LEVELS, false, 0>), grid, dim3(256), 0, st, S, L, WS, d);
     }
 }
 
