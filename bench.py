@@ -361,6 +361,8 @@ def main():
         abytes = total_bytes / max(k_launches, 1)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         pmc = counter_digest(workload_key(scene_name, W, H, limit, traversal), kernel) if world == 1 else None
+        if pmc and not all(k in pmc for k in ("kernel_ms", "valu_issue_frac", "wait_frac")):
+            pmc = None      # (a kernel the profiled run of this workload did not launch)
         # What limits the kernel is read from the counters of this workload when they have been collected; the achieved
         # figure itself is the prescribed one: algorithmic bytes of the reference's data layout over the measured duration.
         bound = "hbm"
