@@ -24,8 +24,8 @@ struct alignas(64) RtNodeRec {
     float lo[3];
     float mid[3];
     float hi[3];
+    uint32_t first_id;    // a leaf: RtTriRec::dup_first of its first triangle (the one carried in the box fields); next to hi[2]: one 8-byte load
     uint32_t parent;      // record index of the parent | octant << 27 (RT_NO_PARENT for the root)
-    uint32_t first_id;    // a leaf: RtTriRec::dup_first of its first triangle (the one carried in the box fields)
     uint32_t pad;
 };
 #define RT_NO_PARENT 0xFFFFFFFFu

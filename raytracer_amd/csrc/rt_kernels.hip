@@ -408,6 +408,11 @@ DEVI TriData load_triangle(const RtTriRec *tr) {
     d.e2z = u2f(q2.x); d.id = q2.y;
     return d;
 }
+// Keeps the loads of a record where they are written.  Without it the compiler moves the load of the first vertex into the
+// branch of the intersection test that needs it (behind the determinant check), where it costs a second memory round trip per test.
+DEVI void pin_triangle(TriData &d) {
+    asm volatile("" : "+v"(d.q0.x), "+v"(d.q0.y), "+v"(d.q0.z), "+v"(d.q0.w), "+v"(d.q1.x), "+v"(d.q1.y), "+v"(d.q1.z), "+v"(d.q1.w), "+v"(d.e2z), "+v"(d.id));
+}
 DEVI float ray_triangle(const Ray &r, const TriData &d) {
     const f3 v1 = F3(d.q0.x, d.q0.y, d.q0.z), e1 = F3(d.q0.w, d.q1.x, d.q1.y), e2 = F3(d.q1.z, d.q1.w, d.e2z);
     const f3 pvec = cross3(r.dir, e2);
@@ -485,17 +490,23 @@ DEVI NodeData unpack_node(const uint4 w0, const float4 w1, const float4 w2, floa
 }
 DEVI NodeData load_node(const RtDeviceScene &S, uint32_t ni) {
     const uint4 *rec = reinterpret_cast<const uint4 *>(S.nodes + ni);
-    const uint4 w3 = rec[3];     // hi.z, parent, first_id, pad
-    return unpack_node(rec[0], reinterpret_cast<const float4 *>(rec)[1], reinterpret_cast<const float4 *>(rec)[2], u2f(w3.x), w3.z);
+    const uint4 w3 = rec[3];     // hi.z, first_id, parent, pad
+    return unpack_node(rec[0], reinterpret_cast<const float4 *>(rec)[1], reinterpret_cast<const float4 *>(rec)[2], u2f(w3.x), w3.y);
 }
 // The records of the top three levels of the tree (the first RT_TOP_RECORDS records: the root's block, its children's block and
 // their blocks), which every ray that enters the octree visits, staged once per workgroup in LDS.
-struct TopLevels { uint4 q[RT_TOP_RECORDS][4]; };
-DEVI void stage_top_levels(TopLevels *top, const RtDeviceScene &S) {      // the caller's next barrier publishes the copy
+// Beside them, for the exact near-first order, the records of the scene's face-coplanar triangles (RtDeviceScene::risky_tris), which
+// every ray is tested against before it starts.
+struct TopLevels { uint4 q[RT_TOP_RECORDS][4]; uint4 risky[RT_MAX_RISKY][3]; };
+DEVI void stage_top_levels(TopLevels *top, const RtDeviceScene &S, bool with_risky) {      // the caller's next barrier publishes the copy
     const uint32_t n = min(S.n_nodes, RT_TOP_RECORDS) * 4u;
     const uint4 *src = reinterpret_cast<const uint4 *>(S.nodes);
     uint4 *dst = &top->q[0][0];
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    if (with_risky && S.n_risky <= RT_MAX_RISKY) {
+        const uint4 *rs = reinterpret_cast<const uint4 *>(S.risky_tris);
+        for (uint32_t i = threadIdx.x; i < S.n_risky * 3u; i += blockDim.x) top->risky[i / 3u][i % 3u] = rs[i];
+    }
 }
 template <bool COUNT>
 DEVI NodeData load_node(const RtDeviceScene &S, const TopLevels *top, uint32_t ni, Counters &cn) {
@@ -503,7 +514,7 @@ DEVI NodeData load_node(const RtDeviceScene &S, const TopLevels *top, uint32_t n
         if (COUNT) cn.lds_pops++;
         const uint4 *rec = top->q[ni];
         const uint4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
-        return unpack_node(a, make_float4(u2f(b.x), u2f(b.y), u2f(b.z), u2f(b.w)), make_float4(u2f(c.x), u2f(c.y), u2f(c.z), u2f(c.w)), u2f(d.x), d.z);
+        return unpack_node(a, make_float4(u2f(b.x), u2f(b.y), u2f(b.z), u2f(b.w)), make_float4(u2f(c.x), u2f(c.y), u2f(c.z), u2f(c.w)), u2f(d.x), d.y);
     }
     return load_node(S, ni);
 }
@@ -618,9 +629,16 @@ struct Exact {
     bool slot;                // the reference's SLOT is wanted (step 2), not only its distance and triangle
     DEVI void begin(float c0, bool want_slot) { best_rank = 0; best_id = 0; post_q = post_end = 0; closest0 = c0; nf = true; tie = false; slot = want_slot; }
 };
-DEVI bool hits_risky(const RtDeviceScene &S, const Ray &r) {
+DEVI bool hits_risky(const RtDeviceScene &S, const TopLevels *top, const Ray &r) {
     bool hit = false;
-    for (uint32_t k = 0; k < S.n_risky; k++) hit = hit || ray_triangle(r, load_triangle(S.risky_tris + k)) >= 0.0f;
+    for (uint32_t k = 0; k < S.n_risky; k++) {
+        const uint4 a = top->risky[k][0], b = top->risky[k][1], c = top->risky[k][2];
+        TriData d;
+        d.q0 = make_float4(u2f(a.x), u2f(a.y), u2f(a.z), u2f(a.w));
+        d.q1 = make_float4(u2f(b.x), u2f(b.y), u2f(b.z), u2f(b.w));
+        d.e2z = u2f(c.x); d.id = c.y;
+        hit = hit || ray_triangle(r, d) >= 0.0f;
+    }
     return hit;
 }
 // EXACT: 0 = plain traversal; 1 = exact near-first for segments whose slot nobody observes (ties between different triangles only);
@@ -648,6 +666,8 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
             TriData td[TRI_BATCH];
 #pragma unroll
             for (uint32_t k = 0; k < TRI_BATCH; k++) td[k] = load_triangle(S.tris + min(w.tri_i + k, w.tri_end - 1u));
+#pragma unroll
+            for (uint32_t k = 0; k < TRI_BATCH; k++) pin_triangle(td[k]);
 #pragma unroll
             for (uint32_t k = 0; k < TRI_BATCH; k++) {
                 if (w.tri_i + k < w.tri_end) accept_hit<EXACT>(ray_triangle(r, td[k]), w.tri_i + k, td[k].id, w.node.rank, closest, closest_tri, tri_hit, x);
@@ -711,6 +731,7 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
             active = false;
         } else {
             w.node = load_node<COUNT>(S, top, st.pop_node(w.key), cn);
+            if (EXACT) asm volatile("" : "+v"(w.node.first_id));    // (fetched with the rest of the record, not in a round trip of its own where a leaf needs it)
             if (COUNT) { cn.pops++; cn.tri_tests += w.node.tri_count; cn.box_tests += __popc(w.node.child_mask); }
             w.tri_i = w.node.tri_start; w.tri_end = w.node.tri_start + w.node.tri_count;
             if (w.node.child_mask == 0 && w.node.tri_count != 0) {   // a leaf's record holds its first triangle
@@ -1427,7 +1448,7 @@ template <int LEVELS, bool COUNT, int EXACT>
 __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
     __shared__ TopLevels lds_top;
-    stage_top_levels(&lds_top, S);
+    stage_top_levels(&lds_top, S, EXACT != 0);
     __syncthreads();
     Exact x;
     x.begin(0.0f, false);
@@ -1477,7 +1498,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
                 walk.begin(st, order_key(ray, L.near_first != 0u));
                 if (EXACT) {
                     x.begin(closest, want_slot);
-                    if (hits_risky(S, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
+                    if (hits_risky(S, &lds_top, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
                 }
                 has = true;
                 if (COUNT) cn.entered++;
@@ -1610,7 +1631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
     __shared__ SphereLds lds_sph;
     __shared__ PortalBasis lds_portals[2];
     __shared__ TopLevels lds_top;
-    stage_top_levels(&lds_top, S);
+    stage_top_levels(&lds_top, S, EXACT != 0);
     stage_spheres(&lds_sph, c_spheres);
     stage_portals(lds_portals, L.u);
     Exact x;
@@ -1725,7 +1746,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                     walk.begin(st, order_key(ray, L.near_first != 0u));
                     if (EXACT) {
                         x.begin(closest, seg == 0u && L.hit_slot != nullptr);
-                        if (hits_risky(S, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
+                        if (hits_risky(S, &lds_top, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
                     }
                     traversing = true;
                 }
