@@ -1331,15 +1331,17 @@ __global__ __launch_bounds__(1024) void order_kernel(uint32_t *__restrict__ cost
 // into ranges of RANGE slots, each owned by one workgroup for the whole frame: at depth 0 a range holds four 16x16
 // pixel tiles; the paths of a range that survive a depth are compacted to the front of the same range of the
 // next-depth planes (a workgroup-local prefix sum: no global atomics), so range b holds live[depth][b] segments.
-// For every depth:
-//   spheres_kernel   all segments, dense: (ray generation at depth 0,) the 84-sphere loop and the root box test;
+//   spheres_kernel   once per frame, all first segments, dense: ray generation, the 84-sphere loop and the root box test;
 //                    the slots of segments that enter the octree are appended to the global traversal queue with
 //                    one atomic per workgroup chunk
+// and then for every depth:
 //   traverse_kernel  persistent waves take batches of the traversal queue; a lane that empties its stack hands its
 //                    result back and the wave refills its idle lanes together once enough of them wait
 //   shade_kernel     all segments, dense: cylinder, portals, hit assembly, scattering; finished paths are tonemapped
-//                    and blended into the target, continuing ones are compacted into the next depth's planes
-// Counters (uint32): ctr[QT_COUNT + (d&1)], ctr[QT_HEAD + (d&1)] traversal queue of depth d.
+//                    and blended into the target, continuing ones are compacted into the next depth's planes -- with
+//                    their sphere loop and root box test done on the spot, and queued for the next traversal
+// Counters (uint32): ctr[QT_COUNT + (d&1)], ctr[QT_HEAD + (d&1)] traversal queue of depth d (zeroed for depth d + 1 by
+// the traversal kernel of depth d).
 // ================================================================================================
 enum { QT_COUNT = 0, QT_HEAD = 2 };
 #define RANGE 1024u            // slots per workgroup-owned range (4 chunks of 256)
@@ -1377,63 +1379,50 @@ __global__ void primary_sphere_kernel(RtLaunch L, float4 *__restrict__ prim) {
     prim[i] = make_float4(oc.x, oc.y, oc.z, dot3(oc, oc) - s.w * s.w);
 }
 
-template <bool D0>
-__global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles) {
+// The first segment of every path of the frame: ray generation, the sphere loop, the root box test.
+__global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t n_tiles) {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t lds_base;
     __shared__ SphereLds lds_sph;
-    stage_spheres(&lds_sph, D0 ? WS.prim : c_spheres);
+    stage_spheres(&lds_sph, WS.prim);
     __syncthreads();
-    const uint32_t cur = depth & 1u;
-    float4 *__restrict__ A = WS.pos_seed[cur];
-    float4 *__restrict__ B = WS.dir_pix[cur];
+    float4 *__restrict__ A = WS.pos_seed[0];
+    float4 *__restrict__ B = WS.dir_pix[0];
     const uint32_t lo = blockIdx.x * RANGE;
-    const uint32_t count = D0 ? min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u) : WS.live[cur][blockIdx.x];
+    const uint32_t count = min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u);
     const bool counting = L.counters != nullptr;
     uint32_t n_sph = 0;
     for (uint32_t off = 0; off < count; off += 256u) {
         const uint32_t slot = lo + off + threadIdx.x;
-        bool valid = off + threadIdx.x < count;
+        const PixelId p = pixel_of(L, blockIdx.x * (RANGE / 256u) + off / 256u, threadIdx.x);
+        const bool valid = p.active;
         Ray ray;
         float closest = __builtin_inff();
         uint32_t closest_i = 0;
         bool enter = false;
-        if (D0) {
-            const PixelId p = pixel_of(L, blockIdx.x * (RANGE / 256u) + off / 256u, threadIdx.x);
-            valid = p.active;
-            float seed_base = 0.0f;
-            ray.pos = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]);
-            ray.dir = F3(0.0f, 0.0f, 1.0f);
-            if (valid) {
-                float nx, ny;
-                pixel_ndc(L, p, nx, ny);
-                generate_ray(L.u, nx, ny, ray.dir, seed_base);
-            }
-            A[slot] = make_float4(ray.pos.x, ray.pos.y, ray.pos.z, seed_base);
-            B[slot] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, u2f(valid ? (uint32_t)p.pi : 0xFFFFFFFFu));
-            WS.color[cur][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            if (valid) {
-                ray.inv = rcp3(ray.dir);
-                SPHERE_LOOP(true, lds_sph, ray, closest, closest_i, counting ? &n_sph : nullptr);
-                enter = root_box_test(S, ray, closest);
-            }
-        } else if (valid) {
-            const float4 a = A[slot], b = B[slot];
-            ray.pos = F3(a.x, a.y, a.z);
-            ray.dir = F3(b.x, b.y, b.z);
+        float seed_base = 0.0f;
+        ray.pos = F3(L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2]);
+        ray.dir = F3(0.0f, 0.0f, 1.0f);
+        if (valid) {
+            float nx, ny;
+            pixel_ndc(L, p, nx, ny);
+            generate_ray(L.u, nx, ny, ray.dir, seed_base);
+        }
+        A[slot] = make_float4(ray.pos.x, ray.pos.y, ray.pos.z, seed_base);
+        B[slot] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, u2f(valid ? (uint32_t)p.pi : 0xFFFFFFFFu));
+        WS.color[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        if (valid) {
             ray.inv = rcp3(ray.dir);
-            SPHERE_LOOP(false, lds_sph, ray, closest, closest_i, counting ? &n_sph : nullptr);
+            SPHERE_LOOP(true, lds_sph, ray, closest, closest_i, counting ? &n_sph : nullptr);
             enter = root_box_test(S, ray, closest);
         }
-        if (D0 || valid) {
-            WS.t[slot] = closest;
-            WS.sphere[slot] = closest_i;
-            WS.tri[slot] = 0u;
-        }
+        WS.t[slot] = closest;
+        WS.sphere[slot] = closest_i;
+        WS.tri[slot] = 0u;
         uint32_t total;
         const uint32_t rank = block_rank(enter, lds4, total);
         if (total) {   // workgroup-uniform
-            if (threadIdx.x == 0) lds_base = atomicAdd(&WS.ctr[QT_COUNT + cur], total);
+            if (threadIdx.x == 0) lds_base = atomicAdd(&WS.ctr[QT_COUNT], total);
             __syncthreads();
             if (enter) WS.qt[lds_base + rank] = slot;
         }
@@ -1461,6 +1450,8 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
     const float4 *__restrict__ B = WS.dir_pix[cur];
     uint32_t *ctr = WS.ctr;
     const uint32_t qt_count = ctr[QT_COUNT + cur];
+    // the queue of the other parity: read last by the previous depth's traversal, filled next by the shade_kernel that follows this launch
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[QT_COUNT + (cur ^ 1u)] = 0; ctr[QT_HEAD + (cur ^ 1u)] = 0; }
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1521,14 +1512,18 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
 template <bool D0, bool COUNT>
 __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles) {
     __shared__ uint32_t lds4[4];
+    __shared__ uint32_t lds_base;
     __shared__ PortalBasis lds_portals[2];
+    __shared__ SphereLds lds_sph;
+    stage_spheres(&lds_sph, c_spheres);      // (published by the barrier inside stage_portals)
     stage_portals(lds_portals, L.u);
     const uint32_t cur = depth & 1u, nxt = cur ^ 1u;
     const float4 *__restrict__ A = WS.pos_seed[cur];
     const float4 *__restrict__ B = WS.dir_pix[cur];
     const float4 *__restrict__ C = WS.color[cur];
     uint32_t *ctr = WS.ctr;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[QT_COUNT + nxt] = 0; ctr[QT_HEAD + nxt] = 0; }   // next depth's traversal queue
+    const bool counting = L.counters != nullptr;
+    uint32_t n_sph = 0;
     const uint32_t lo = blockIdx.x * RANGE;
     const uint32_t count = D0 ? min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u) : WS.live[cur][blockIdx.x];
     uint32_t out_count = 0;    // workgroup-uniform: survivors of this range so far
@@ -1582,17 +1577,44 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
                 }
             }
         }
+        // The next segment's sphere loop and root box test run here, on the ray still in registers (what spheres_kernel does for
+        // the first segment): its planes are written once, and the segments that enter the octree go to the next depth's queue.
+        float nclosest = __builtin_inff();
+        uint32_t nclosest_i = 0;
+        bool enter = false;
+        if (cont) {
+            Ray nr;
+            nr.pos = F3(na.x, na.y, na.z);
+            nr.dir = F3(nb.x, nb.y, nb.z);
+            nr.inv = rcp3(nr.dir);
+            SPHERE_LOOP(false, lds_sph, nr, nclosest, nclosest_i, counting ? &n_sph : nullptr);
+            enter = root_box_test(S, nr, nclosest);
+        }
         uint32_t total;
         const uint32_t rank = block_rank(cont, lds4, total);
-        if (cont) {
-            const uint32_t ni = lo + out_count + rank;   // never ahead of the slots this workgroup still has to read: other planes
+        const uint32_t ni = lo + out_count + rank;       // never ahead of the slots this workgroup still has to read (all of this
+        if (cont) {                                      // chunk's were read before the barriers of block_rank)
             WS.pos_seed[nxt][ni] = na;
             WS.dir_pix[nxt][ni] = nb;
             WS.color[nxt][ni] = nc;
+            WS.t[ni] = nclosest;
+            WS.sphere[ni] = nclosest_i;
+            WS.tri[ni] = 0u;
         }
         out_count += total;
+        uint32_t total_e;
+        const uint32_t rank_e = block_rank(enter, lds4, total_e);
+        if (total_e) {   // workgroup-uniform
+            if (threadIdx.x == 0) lds_base = atomicAdd(&ctr[QT_COUNT + nxt], total_e);
+            __syncthreads();
+            if (enter) WS.qt[lds_base + rank_e] = ni;
+        }
     }
     if (threadIdx.x == 0) WS.live[nxt][blockIdx.x] = out_count;
+    if (counting) {
+        const uint32_t v = wave_sum(n_sph);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&L.counters[6], (unsigned long long)v);
+    }
     if (COUNT && L.counters) flush_counters(L.counters, cn);
 }
 
@@ -1896,8 +1918,7 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         // whereas asking the device whether any path is left would block the caller inside an enqueue)
         const uint32_t limit = L.u.max_recursion_limit;
         for (uint32_t d = 0; d < limit; d++) {
-            if (d == 0) hipLaunchKernelGGL((spheres_kernel<true>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
-            else hipLaunchKernelGGL((spheres_kernel<false>), grid, dim3(256), 0, st, S, L, *WS, d, n_tiles);
+            if (d == 0) hipLaunchKernelGGL(spheres_kernel, grid, dim3(256), 0, st, S, L, *WS, n_tiles);    // (later depths: inside the previous shade_kernel)
             if (S.n_nodes) {
                 const bool t = timed && probe->used < probe->capacity;
                 if (t) mark(0);
