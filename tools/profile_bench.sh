@@ -7,6 +7,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROF_DIR:-prof}; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 python3 $R/bench.py --no-north-star "$@" > $O/bench.json || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --no-north-star --no-cpu-baseline "$@" > $O/bench_under_rocprof.json || exit 1
+find $O/stats -name '*kernel_trace.csv' -delete      # (tens of MB per run; the summaries are made from *kernel_stats.csv)
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" \
             "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
