@@ -71,7 +71,7 @@ int noalloc_setup(int dev) {
 struct rt_scene {
     int device = 0;
     RtDeviceScene d{};
-    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_dup = nullptr, *d_risky = nullptr, *d_sky = nullptr;
+    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_dup = nullptr, *d_risky = nullptr, *d_sky = nullptr;
     unsigned long long *d_counters = nullptr;
     bool counting = false;
     // staging for host-memory targets
@@ -344,9 +344,10 @@ int rt_scene_create_from(const float *vertices, const float *normals, size_t n_v
     t_flatten = ms_since(t_phase); t_phase = now();
     if (n_ref) {
         hipError_t e = hipMalloc(&s->d_tris, n_ref * sizeof(RtTriRec));
+        if (e == hipSuccess) e = hipMalloc(&s->d_shade, n_ref * sizeof(RtShadeRec));
         if (e == hipSuccess) e = hipMalloc(&s->d_dup, n_ref * sizeof(uint32_t));
-        if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes, (RtTriRec *)s->d_tris, (uint32_t *)s->d_dup,
-                                                                    (RtTriRec **)&s->d_risky, &s->d.n_risky);
+        if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const float *)s->d_normals, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes,
+                                                                    (RtTriRec *)s->d_tris, (RtShadeRec *)s->d_shade, (uint32_t *)s->d_dup, (RtTriRec **)&s->d_risky, &s->d.n_risky);
         if (e != hipSuccess) { rt_scene_destroy(s); return fail(e == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "triangle records: %s", hipGetErrorString(e)); }
     }
     if (hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_counters, 0, 128) != hipSuccess) {
@@ -354,7 +355,7 @@ int rt_scene_create_from(const float *vertices, const float *normals, size_t n_v
         return fail(RT_ENOMEM, "cannot allocate counters");
     }
     s->d.vertices = (const float *)s->d_vertices; s->d.normals = (const float *)s->d_normals; s->d.tri_refs = (const uint32_t *)s->d_refs;
-    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.risky_tris = (const RtTriRec *)s->d_risky; s->d.sky = nullptr;
+    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.shade = (const RtShadeRec *)s->d_shade; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.risky_tris = (const RtTriRec *)s->d_risky; s->d.sky = nullptr;
     s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = nb.n_nodes;
     s->d.sky_w = s->d.sky_h = 0;
     for (int k = 0; k < 3; k++) { s->d.bounds_min[k] = bounds_min[k]; s->d.bounds_max[k] = bounds_max[k]; }
@@ -878,7 +879,7 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
 int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     DeviceGuard guard(s->device);
-    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_dup, s->d_risky, s->d_sky, s->d_counters};
+    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_shade, s->d_dup, s->d_risky, s->d_sky, s->d_counters};
     for (void *q : p) if (q) (void)hipFree(q);
     free_staging(s);
     for (rt_scene::Sub &sb : s->sub) {

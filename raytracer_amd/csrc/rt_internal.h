@@ -50,12 +50,24 @@ struct alignas(16) RtTriRec {
 };
 static_assert(sizeof(RtTriRec) == 48, "triangle record is three 16-byte quads");
 
+// What shading a triangle hit reads (frag:541-556), gathered once per scene into one record per reference: the first vertex and
+// the two edges -- the barycentric weights are formed from b - a, c - a and p - a (frag:215-217), and the first two ARE the edges,
+// by the same IEEE subtractions --, the three vertex normals and the material.  A shaded hit then costs five 16-byte loads from
+// one or two cache lines instead of seven loads from seven scattered lines (index record, three vertices, three normals).
+struct alignas(16) RtShadeRec {
+    float a[3], e1[3], e2[3];
+    float n1[3], n2[3], n3[3];
+    uint32_t material, pad;
+};
+static_assert(sizeof(RtShadeRec) == 80, "shading record is five 16-byte quads");
+
 struct RtDeviceScene {
     const float *vertices;     // [n_vert][4]
     const float *normals;      // [n_vert][4]
     const uint32_t *tri_refs;  // [n_ref][4]
     const RtNodeRec *nodes;    // [n_nodes]
     const RtTriRec *tris;      // [n_ref]
+    const RtShadeRec *shade;   // [n_ref]
     const uint32_t *dup_parent; // [n_ref]: by position in the sorted reference array (see RtTriRec): `parent` word of the node holding that reference
     // Triangles that lie IN a face plane of a node that references them (all three vertices share a coordinate equal to the
     // box bound; the triangles on the faces of the root box, whose bounds are the extreme vertices, are such triangles).  The
@@ -155,8 +167,8 @@ struct RtNodeBuild { RtNodeRec *nodes; uint32_t n_nodes, max_depth, error, error
 int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3], RtNodeBuild *out);
 // dup_parent: n_ref words (see RtDeviceScene).
 // risky / n_risky: see RtDeviceScene (*risky is hipMalloc'ed when *n_risky is in 1..RT_MAX_RISKY; the caller frees).
-int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent,
-                           RtTriRec **risky, uint32_t *n_risky);
+int rt_build_scene_records(const float *vertices, const float *normals, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, RtShadeRec *shade,
+                           uint32_t *dup_parent, RtTriRec **risky, uint32_t *n_risky);
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
 // pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:

@@ -813,14 +813,9 @@ DEVI float ray_portal(const Ray &r, f3 ppos, f3 pn, const PortalBasis &pb, float
     return __builtin_inff();
 }
 
-DEVI f3 load_xyz(const float *base, uint32_t i) {
-    const float4 v = *reinterpret_cast<const float4 *>(base + 4 * (size_t)i);
-    return F3(v.x, v.y, v.z);
-}
-
-// frag:215-230
-DEVI f3 barycentric(f3 p, f3 a, f3 b, f3 c) {
-    const f3 v0 = b - a, v1 = c - a, v2 = p - a;
+// frag:215-230 with the two edges v0 = b - a and v1 = c - a taken from the shading record (RtShadeRec: the same subtractions, done once per scene)
+DEVI f3 barycentric(f3 p, f3 a, f3 v0, f3 v1) {
+    const f3 v2 = p - a;
     const float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
     const float denom = d00 * d11 - d01 * d01;
     const float v = div_ieee(d11 * d20 - d01 * d21, denom);
@@ -868,12 +863,11 @@ DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const
         h.normal = cyl_n;
         if (tap) { tap->kind = RT_HIT_CYLINDER; tap->slot = 0; tap->t = closest; }
     } else if (tri_hit) {
-        const uint4 ind = *reinterpret_cast<const uint4 *>(S.tri_refs + 4 * (size_t)closest_tri);
-        const f3 a = load_xyz(S.vertices, ind.x), b = load_xyz(S.vertices, ind.y), c = load_xyz(S.vertices, ind.z);
-        const f3 n1 = load_xyz(S.normals, ind.x), n2 = load_xyz(S.normals, ind.y), n3 = load_xyz(S.normals, ind.z);
-        const f3 uvw = barycentric(h.position, a, b, c);
-        h.normal = (n1 * uvw.x + n2 * uvw.y) + n3 * uvw.z;
-        h.material_id = ind.w;
+        const float4 *sr = reinterpret_cast<const float4 *>(S.shade + closest_tri);      // frag:541-549 from one record
+        const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
+        const f3 uvw = barycentric(h.position, F3(q0.x, q0.y, q0.z), F3(q0.w, q1.x, q1.y), F3(q1.z, q1.w, q2.x));
+        h.normal = (F3(q2.y, q2.z, q2.w) * uvw.x + F3(q3.x, q3.y, q3.z) * uvw.y) + F3(q3.w, q4.x, q4.y) * uvw.z;
+        h.material_id = f2u(q4.z);
         if (COUNT) cn.tri_shaded++;
         if (tap) { tap->kind = RT_HIT_TRIANGLE; tap->slot = closest_tri; tap->t = closest; }
     } else {

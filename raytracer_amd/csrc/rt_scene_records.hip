@@ -172,7 +172,8 @@ __global__ __launch_bounds__(BLOCK) void dup_write_kernel(const uint32_t *__rest
     dup_parent[i] = slot_parent[slot];
 }
 
-__global__ __launch_bounds__(BLOCK) void triangle_records_kernel(const float4 *__restrict__ vertices, const uint4 *__restrict__ refs, uint32_t n_ref, RtTriRec *__restrict__ tris) {
+__global__ __launch_bounds__(BLOCK) void triangle_records_kernel(const float4 *__restrict__ vertices, const float4 *__restrict__ normals, const uint4 *__restrict__ refs, uint32_t n_ref,
+                                                                 RtTriRec *__restrict__ tris, RtShadeRec *__restrict__ shade) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_ref) return;
     const uint4 t = refs[i];
@@ -183,6 +184,16 @@ __global__ __launch_bounds__(BLOCK) void triangle_records_kernel(const float4 *_
     r.e2x = c.x - a.x; r.e2y = c.y - a.y; r.e2z = c.z - a.z;
     r.dup_first = r.dup_pos = i; r.pad = 0;
     tris[i] = r;
+    const float4 n1 = normals[t.x], n2 = normals[t.y], n3 = normals[t.z];   // frag:543-545
+    RtShadeRec h;
+    h.a[0] = a.x; h.a[1] = a.y; h.a[2] = a.z;
+    h.e1[0] = r.e1x; h.e1[1] = r.e1y; h.e1[2] = r.e1z;                      // frag:216-217: b - a, c - a
+    h.e2[0] = r.e2x; h.e2[1] = r.e2y; h.e2[2] = r.e2z;
+    h.n1[0] = n1.x; h.n1[1] = n1.y; h.n1[2] = n1.z;
+    h.n2[0] = n2.x; h.n2[1] = n2.y; h.n2[2] = n2.z;
+    h.n3[0] = n3.x; h.n3[1] = n3.y; h.n3[2] = n3.z;
+    h.material = t.w; h.pad = 0;
+    shade[i] = h;
 }
 
 __global__ __launch_bounds__(BLOCK) void leaf_triangle_kernel(RtNodeRec *__restrict__ nodes, uint32_t n_nodes, const RtTriRec *__restrict__ tris) {
@@ -298,10 +309,10 @@ int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref,
     return RT_OK;
 }
 
-int rt_build_scene_records(const float *vertices, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, uint32_t *dup_parent,
-                           RtTriRec **risky, uint32_t *n_risky) {
+int rt_build_scene_records(const float *vertices, const float *normals, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, RtShadeRec *shade,
+                           uint32_t *dup_parent, RtTriRec **risky, uint32_t *n_risky) {
     *risky = nullptr; *n_risky = 0;
-    if (n_ref) hipLaunchKernelGGL(triangle_records_kernel, dim3(grid_for(n_ref)), dim3(BLOCK), 0, nullptr, (const float4 *)vertices, (const uint4 *)tri_refs, n_ref, tris);
+    if (n_ref) hipLaunchKernelGGL(triangle_records_kernel, dim3(grid_for(n_ref)), dim3(BLOCK), 0, nullptr, (const float4 *)vertices, (const float4 *)normals, (const uint4 *)tri_refs, n_ref, tris, shade);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_ref == 0) return (int)e;
     // The references of each triangle, sorted by the rank of the node that holds them (see RtTriRec): a stable radix sort by
