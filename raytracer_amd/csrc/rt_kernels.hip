@@ -1363,6 +1363,29 @@ DEVI uint32_t block_rank(bool pred, uint32_t *lds4, uint32_t &total) {
     return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// The same for two predicates at once (one pair of barriers): lds8 holds the 4 + 4 per-wave counts.
+DEVI void block_rank2(bool pa, bool pb, uint32_t *lds8, uint32_t &rank_a, uint32_t &total_a, uint32_t &rank_b, uint32_t &total_b) {
+    const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __syncthreads();                       // lds8 may still be read from the previous use
+    if (lane == 0) { lds8[wave] = (uint32_t)__popcll(ma); lds8[4u + wave] = (uint32_t)__popcll(mb); }
+    __syncthreads();
+    const uint32_t a0 = lds8[0], a1 = lds8[1], a2 = lds8[2], a3 = lds8[3], b0 = lds8[4], b1 = lds8[5], b2 = lds8[6], b3 = lds8[7];
+    total_a = a0 + a1 + a2 + a3; total_b = b0 + b1 + b2 + b3;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    rank_a = (wave == 0 ? 0u : (wave == 1 ? a0 : (wave == 2 ? a0 + a1 : a0 + a1 + a2))) + (uint32_t)__popcll(ma & below);
+    rank_b = (wave == 0 ? 0u : (wave == 1 ? b0 : (wave == 2 ? b0 + b1 : b0 + b1 + b2))) + (uint32_t)__popcll(mb & below);
+}
+// The slots of a workgroup's range that enter the octree are collected in LDS and appended to the traversal queue with ONE
+// atomic per workgroup: adds to one address serialise in the L2 at several nanoseconds each, and a 4K frame has 32 400 chunks.
+DEVI void flush_queue(const uint32_t *lds_q, uint32_t n, uint32_t *lds_base, uint32_t *counter, uint32_t *__restrict__ qt) {
+    if (n == 0) return;                    // workgroup-uniform
+    if (threadIdx.x == 0) *lds_base = atomicAdd(counter, n);
+    __syncthreads();                       // (also publishes the last chunk's entries of lds_q)
+    const uint32_t base = *lds_base;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) qt[base + i] = lds_q[i];
+}
+
 // Per-frame constants of the spheres as seen from the camera: (oc.xyz, c) with oc = camera - centre and
 // c = dot(oc,oc) - r*r, the values every primary ray would compute (frag:234,236).
 __global__ void primary_sphere_kernel(RtLaunch L, float4 *__restrict__ prim) {
@@ -1377,9 +1400,11 @@ __global__ void primary_sphere_kernel(RtLaunch L, float4 *__restrict__ prim) {
 __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t n_tiles) {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t lds_base;
+    __shared__ uint32_t lds_q[RANGE];
     __shared__ SphereLds lds_sph;
     stage_spheres(&lds_sph, WS.prim);
     __syncthreads();
+    uint32_t q_count = 0;      // workgroup-uniform: entries of lds_q
     float4 *__restrict__ A = WS.pos_seed[0];
     float4 *__restrict__ B = WS.dir_pix[0];
     const uint32_t lo = blockIdx.x * RANGE;
@@ -1415,12 +1440,10 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
         WS.tri[slot] = 0u;
         uint32_t total;
         const uint32_t rank = block_rank(enter, lds4, total);
-        if (total) {   // workgroup-uniform
-            if (threadIdx.x == 0) lds_base = atomicAdd(&WS.ctr[QT_COUNT], total);
-            __syncthreads();
-            if (enter) WS.qt[lds_base + rank] = slot;
-        }
+        if (enter) lds_q[q_count + rank] = slot;
+        q_count += total;
     }
+    flush_queue(lds_q, q_count, &lds_base, &WS.ctr[QT_COUNT], WS.qt);
     if (counting) {
         const uint32_t v = wave_sum(n_sph);
         if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&L.counters[6], (unsigned long long)v);
@@ -1505,8 +1528,9 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
 
 template <bool D0, bool COUNT>
 __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth, uint32_t n_tiles) {
-    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t lds8[8];
     __shared__ uint32_t lds_base;
+    __shared__ uint32_t lds_q[RANGE];
     __shared__ PortalBasis lds_portals[2];
     __shared__ SphereLds lds_sph;
     stage_spheres(&lds_sph, c_spheres);      // (published by the barrier inside stage_portals)
@@ -1521,6 +1545,7 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
     const uint32_t lo = blockIdx.x * RANGE;
     const uint32_t count = D0 ? min(RANGE, (n_tiles - blockIdx.x * (RANGE / 256u)) * 256u) : WS.live[cur][blockIdx.x];
     uint32_t out_count = 0;    // workgroup-uniform: survivors of this range so far
+    uint32_t q_count = 0;      // workgroup-uniform: of them, those that enter the octree (entries of lds_q)
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t off = 0; off < count; off += 256u) {
         const uint32_t slot = lo + off + threadIdx.x;
@@ -1584,10 +1609,10 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
             SPHERE_LOOP(false, lds_sph, nr, nclosest, nclosest_i, counting ? &n_sph : nullptr);
             enter = root_box_test(S, nr, nclosest);
         }
-        uint32_t total;
-        const uint32_t rank = block_rank(cont, lds4, total);
+        uint32_t total, rank, total_e, rank_e;
+        block_rank2(cont, enter, lds8, rank, total, rank_e, total_e);
         const uint32_t ni = lo + out_count + rank;       // never ahead of the slots this workgroup still has to read (all of this
-        if (cont) {                                      // chunk's were read before the barriers of block_rank)
+        if (cont) {                                      // chunk's were read before the barriers of block_rank2)
             WS.pos_seed[nxt][ni] = na;
             WS.dir_pix[nxt][ni] = nb;
             WS.color[nxt][ni] = nc;
@@ -1596,14 +1621,10 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
             WS.tri[ni] = 0u;
         }
         out_count += total;
-        uint32_t total_e;
-        const uint32_t rank_e = block_rank(enter, lds4, total_e);
-        if (total_e) {   // workgroup-uniform
-            if (threadIdx.x == 0) lds_base = atomicAdd(&ctr[QT_COUNT + nxt], total_e);
-            __syncthreads();
-            if (enter) WS.qt[lds_base + rank_e] = ni;
-        }
+        if (enter) lds_q[q_count + rank_e] = ni;
+        q_count += total_e;
     }
+    flush_queue(lds_q, q_count, &lds_base, &ctr[QT_COUNT + nxt], WS.qt);
     if (threadIdx.x == 0) WS.live[nxt][blockIdx.x] = out_count;
     if (counting) {
         const uint32_t v = wave_sum(n_sph);
