@@ -354,7 +354,9 @@ int rt_scene_create_from(const float *vertices, const float *normals, size_t n_v
         rt_scene_destroy(s);
         return fail(RT_ENOMEM, "cannot allocate counters");
     }
-    s->d.vertices = (const float *)s->d_vertices; s->d.normals = (const float *)s->d_normals; s->d.tri_refs = (const uint32_t *)s->d_refs;
+    // the uploaded arrays have served: every kernel reads the records derived from them (node, triangle and shading records)
+    for (void **q : {&s->d_vertices, &s->d_normals, &s->d_refs}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    s->d.vertices = nullptr; s->d.normals = nullptr; s->d.tri_refs = nullptr;
     s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.shade = (const RtShadeRec *)s->d_shade; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.risky_tris = (const RtTriRec *)s->d_risky; s->d.sky = nullptr;
     s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = nb.n_nodes;
     s->d.sky_w = s->d.sky_h = 0;

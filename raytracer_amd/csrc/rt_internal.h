@@ -62,9 +62,9 @@ struct alignas(16) RtShadeRec {
 static_assert(sizeof(RtShadeRec) == 80, "shading record is five 16-byte quads");
 
 struct RtDeviceScene {
-    const float *vertices;     // [n_vert][4]
-    const float *normals;      // [n_vert][4]
-    const uint32_t *tri_refs;  // [n_ref][4]
+    const float *vertices;     // [n_vert][4]  } the caller's arrays as uploaded: only alive while the records below are derived from them
+    const float *normals;      // [n_vert][4]  } at scene creation, null afterwards
+    const uint32_t *tri_refs;  // [n_ref][4]   }
     const RtNodeRec *nodes;    // [n_nodes]
     const RtTriRec *tris;      // [n_ref]
     const RtShadeRec *shade;   // [n_ref]
