@@ -58,6 +58,10 @@ SCENE_TEXT = {
 }
 
 
+N_CU = 256                        # compute units of an MI355X
+GATHER_CEILING = [2200, 3250]     # lane-loads per us per CU that tools/experiments/gather_bench.hip reaches at 26 / 64 active lanes (64-byte records, L2-resident)
+
+
 def traversal_bytes(st: dict) -> int:
     """Bytes the reference's data layout moves for the counted octree work: per node visit 2 header words + 4 B per
     child pointer; per triangle test a 16 B index record + three 16 B vertices."""
@@ -379,6 +383,16 @@ def main():
                                    "of one launch / that launch's duration (HIP events): an effective rate, not HBM utilisation -- `traffic` and `counters` are the measured side"}
         if pmc:
             rep["roofline"]["counters"] = pmc
+            if "lane_loads_per_launch" in pmc and frame_ms > 0:
+                per_frame = k_launches / steps
+                per_us_cu = lambda v: round(v * per_frame / (frame_ms * 1e3) / N_CU, 1)
+                rep["roofline"]["load_path"] = {
+                    "lane_loads_per_us_per_cu": per_us_cu(pmc["lane_loads_per_launch"]), "l2_requests_per_us_per_cu": per_us_cu(pmc.get("l2_requests_per_launch", 0.0)),
+                    "gather_ceiling_lane_loads_per_us_per_cu": GATHER_CEILING,
+                    "what": "per-lane load instructions (and requests reaching L2) of the dominant kernel's launches over the WHOLE frame time, per compute unit; the ceiling is what "
+                            "tools/experiments/gather_bench.hip measures for chains of dependent fetches of scattered 64-byte records (four 16-byte loads each, one L2 request per "
+                            "four lane-loads) from an L2-resident table at 26 and at 64 active lanes per wave: the deep scenes' traversal (one L2 request per six lane-loads at 25-31 "
+                            "lanes) runs against it; the headline kernel's coherent primary rays hit the vector L1 (one L2 request per 26 lane-loads) and are not bound by it"}
         if achieved > HBM_PEAK_GBS:
             rep["roofline"]["what"] += "; frac > 1 here: most of the records a ray touches are served by the caches"
         aflops = counted_flops(local_tot) / steps

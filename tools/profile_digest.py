@@ -58,6 +58,13 @@ for k, cs in pmc.items():
             d["occupancy_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4.0 / (cyc * N_SIMD)   # SQ_WAVE_CYCLES counts quad-cycles
     if m.get("SQ_ACTIVE_INST_VALU"):
         d["lanes_active_of_64"] = m["SQ_THREAD_CYCLES_VALU"] / m["SQ_ACTIVE_INST_VALU"]
+    if m.get("SQ_INSTS_VMEM_RD") and "lanes_active_of_64" in d:
+        # per-lane load instructions of one launch, taking the lane occupancy of the VALU instructions for that of the loads; with
+        # TCC_HIT + TCC_MISS (requests that reach L2) what tools/experiments/gather_bench.hip measures the load path's ceiling in
+        d["vmem_rd_wave_insts"] = m["SQ_INSTS_VMEM_RD"]
+        d["lane_loads_per_launch"] = m["SQ_INSTS_VMEM_RD"] * d["lanes_active_of_64"]
+    if m.get("TCC_HIT_sum") is not None:
+        d["l2_requests_per_launch"] = m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)
     if m.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in m:
         d["wait_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
     if m.get("TCC_HIT_sum") is not None and (m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)) > 0:
