@@ -373,6 +373,9 @@ def main():
         if pmc:
             hbm_frac = pmc["hbm_bytes_per_launch"] / (pmc["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             cands = {"hbm": hbm_frac, "valu-issue": pmc["valu_issue_frac"]}
+            if kernel == "traverse_kernel" and "lane_loads_per_launch" in pmc and frame_ms > 0:
+                # scattered record fetches that miss the vector L1: measured against what the load path sustains for such fetches
+                cands["load-path (scattered 16-byte loads)"] = pmc["lane_loads_per_launch"] * (k_launches / steps) / (frame_ms * 1e3) / N_CU / GATHER_CEILING[0]
             top = max(cands, key=cands.get)
             bound = top if cands[top] >= 0.5 else f"latency ({top} {cands[top]:.2f} is the nearest ceiling; waves wait {pmc['wait_frac']:.2f} of their lifetime)"
         rep["roofline"] = {"kernel": kernel, "bound": bound, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
