@@ -326,6 +326,8 @@ def main():
             elapsed = float(tmax.item())
 
         # ---- count the work of the timed frames (untimed replay with counters on) ------------------------------
+        if args.pipeline == "auto":
+            sc.set_pipeline(pipeline)    # the replay counts the work of the pipeline that was timed (left alone, the selection looks at the others again now and then)
         sc.set_counting(True)
         tot = {}
         for k in range(steps):
