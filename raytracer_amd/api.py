@@ -29,7 +29,7 @@ HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = r
 
 EXPORTED_SYMBOLS = [
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_render_noalloc", "rt_band_row_count", "rt_scene_stats",
-    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free",
+    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free", "rt_scene_create_from_meshes",
     # include/rt_camera.h (bound in glm_camera.py)
     "rt_vec3_normalize", "rt_camera_init", "rt_camera_set_view", "rt_camera_set_proj", "rt_camera_view_proj", "rt_camera_inv_view_proj", "rt_portal_difference_matrix", "rt_portal_ray",
     "rt_manipulator_init", "rt_manipulator_set_camera", "rt_manipulator_update", "rt_manipulator_key", "rt_manipulator_mouse_move", "rt_manipulator_mouse_wheel",
@@ -124,6 +124,7 @@ def lib():
         L.rt_octree_build.argtypes = [C.POINTER(rt_mesh), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(rt_octree)]
         L.rt_octree_build_device.argtypes = [C.POINTER(rt_mesh), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(rt_octree)]
         L.rt_octree_free.argtypes = [C.POINTER(rt_octree)]
+        L.rt_scene_create_from_meshes.argtypes = [C.POINTER(rt_mesh), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.rt_octree_free.restype = None
         _lib = L
     return _lib
@@ -330,19 +331,25 @@ class Mesh:
         return me
 
 
+def _mesh_array(meshes):
+    """The meshes as the C ABI's rt_mesh array, and the numpy arrays its pointers refer to (to be kept alive by the caller)."""
+    arr = (rt_mesh * max(1, len(meshes)))()
+    keep = []
+    for i, me in enumerate(meshes):
+        v, n, t = (np.ascontiguousarray(me.m_vertecies, np.float32), np.ascontiguousarray(me.m_normals, np.float32), np.ascontiguousarray(me.m_triangles, np.uint32))
+        keep += [v, n, t]
+        arr[i].vertices = v.ctypes.data_as(C.POINTER(C.c_float)); arr[i].normals = n.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].triangles = t.ctypes.data_as(C.POINTER(C.c_uint32)); arr[i].n_vert = len(v); arr[i].n_tri = len(t)
+    return arr, keep
+
+
 class Octree:
     """Octree(meshes, depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_after) -- Octree.hpp:27-36."""
 
     def __init__(self, meshes, depth_limit: int = 18, max_triangles_per_node: int = 10, max_triangles_per_leaf: int = 6,
                  keep_triangles_after_this_many_overlaps: int = 6, *, device: int | None = None):
         """device=None: the host builder; device=i: the same construction with the overlap tests on GPU i (identical arrays)."""
-        arr = (rt_mesh * max(1, len(meshes)))()
-        keep = []
-        for i, me in enumerate(meshes):
-            v, n, t = (np.ascontiguousarray(me.m_vertecies, np.float32), np.ascontiguousarray(me.m_normals, np.float32), np.ascontiguousarray(me.m_triangles, np.uint32))
-            keep += [v, n, t]
-            arr[i].vertices = v.ctypes.data_as(C.POINTER(C.c_float)); arr[i].normals = n.ctypes.data_as(C.POINTER(C.c_float))
-            arr[i].triangles = t.ctypes.data_as(C.POINTER(C.c_uint32)); arr[i].n_vert = len(v); arr[i].n_tri = len(t)
+        arr, keep = _mesh_array(meshes)
         o = rt_octree()
         if device is None:
             _check(lib().rt_octree_build(arr, len(meshes), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, C.byref(o)))
@@ -387,6 +394,23 @@ class Scene:
         _check(lib().rt_scene_create(v.ctypes.data, n.ctypes.data, len(v), t.ctypes.data, len(t), k.ctypes.data, len(k), lo.ctypes.data, hi.ctypes.data, C.byref(h)))
         self._h = h
         self.n_ref, self.n_words = len(t), len(k)
+
+    @staticmethod
+    def from_meshes(meshes, depth_limit: int = 18, max_triangles_per_node: int = 10, max_triangles_per_leaf: int = 6,
+                    keep_triangles_after_this_many_overlaps: int = 6, *, device: int = 0) -> "Scene":
+        """Octree(meshes, ...) and the uploads of App.cpp:22-26 in one call that stays on the device (rt_scene_create_from_meshes);
+        the octree's bounds, which the uniforms need, are left in `bounds_min` / `bounds_max`."""
+        arr, keep = _mesh_array(meshes)
+        lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        h = C.c_void_p()
+        _check(lib().rt_scene_create_from_meshes(arr, len(meshes), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps,
+                                                  int(device), lo.ctypes.data, hi.ctypes.data, C.byref(h)))
+        del keep
+        sc = Scene.__new__(Scene)
+        sc._h = h
+        sc.n_ref = sc.n_words = None
+        sc.bounds_min, sc.bounds_max = lo, hi
+        return sc
 
     @staticmethod
     def from_octree(octree: Octree, device: int | None = None) -> "Scene":

@@ -274,6 +274,8 @@ int rt_set_device(int device) {
     return RT_OK;
 }
 
+extern "C" int rt_internal_swap_device(int device) { const int before = g_device; g_device = device; return before; }
+
 int rt_scene_create(const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
                     const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], rt_scene **out) {
     return rt_scene_create_from(vertices, normals, n_vert, tri_refs, n_ref, nodes, n_words, bounds_min, bounds_max, 0, out);

@@ -34,6 +34,11 @@
 
 #include "rt_build_internal.h"
 
+// rt_api.cpp: scene creation from arrays already in device memory; this thread's rt_set_device choice (-1: none) swapped for another
+extern "C" int rt_scene_create_from(const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
+                                    const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], int source_is_device, rt_scene **out);
+extern "C" int rt_internal_swap_device(int device);
+
 namespace {
 
 using rt_host::Tri;
@@ -271,7 +276,9 @@ struct PhaseClock {          // RT_BUILD_TRACE=1: wall time per phase on stderr
     void report() { if (on) fprintf(stderr, "device octree build ms: upload %.1f | classify+rank+candidates %.1f | candidate ordering (host) %.1f | next level %.1f | flatten %.1f | copy back %.1f\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]); }
 };
 
-int build_on_device(const float *verts, size_t n_vert, const std::vector<Tri> &all, const rt_host::Params &P, rt_octree *out) {
+// scene != nullptr: instead of copying the flattened arrays to the host (`out` is then only given the sizes, bounds and depth), the scene is
+// created from them where they are.
+int build_on_device(const float *verts, const float *norms, size_t n_vert, const std::vector<Tri> &all, const rt_host::Params &P, rt_octree *out, rt_scene **scene = nullptr) {
     PhaseClock clock;
     float root_lo[3], root_hi[3];
     rt_host::root_bounds(verts, all, root_lo, root_hi);
@@ -490,6 +497,18 @@ int build_on_device(const float *verts, size_t n_vert, const std::vector<Tri> &a
     clock.lap(4);
 
     memset(out, 0, sizeof *out);
+    if (scene) {
+        DevBuf d_norms;
+        HIP_OK(d_norms.alloc(n_vert * 16));
+        if (n_vert) HIP_OK(hipMemcpyAsync(d_norms.p, norms, n_vert * 16, hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+        out->n_words = n_words; out->n_ref = n_ref; out->max_depth = max_depth;
+        for (int k = 0; k < 3; k++) { out->bounds_min[k] = root_lo[k]; out->bounds_max[k] = root_hi[k]; }
+        const int rc = rt_scene_create_from(d_verts.as<float>(), d_norms.as<float>(), n_vert, refs_d.as<uint32_t>(), n_ref, words_d.as<uint32_t>(), n_words, root_lo, root_hi, 1, scene);
+        clock.lap(5);
+        clock.report();
+        return rc;
+    }
     out->nodes = (uint32_t *)malloc(std::max<size_t>(1, n_words) * 4);
     out->tri_refs = (uint32_t *)malloc(std::max<size_t>(1, n_ref) * 16);
     auto fail_free = [&](int rc) { free(out->nodes); free(out->tri_refs); memset(out, 0, sizeof *out); return rc; };
@@ -521,10 +540,44 @@ extern "C" int rt_octree_build_device(const rt_mesh *meshes, size_t n_meshes, si
     int rc = rt_host::merge_meshes(meshes, n_meshes, &verts, &norms, &nv, all);
     if (rc == RT_OK) {
         const rt_host::Params P{depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps};
-        rc = build_on_device(verts, nv, all, P, out);
+        rc = build_on_device(verts, norms, nv, all, P, out);
         if (rc == RT_OK) { out->vertices = verts; out->normals = norms; out->n_vert = nv; }
         else { free(verts); free(norms); }
     }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int rt_scene_create_from_meshes(const rt_mesh *meshes, size_t n_meshes, size_t depth_limit, size_t max_triangles_per_node, size_t max_triangles_per_leaf,
+                                           size_t keep_triangles_after_this_many_overlaps, int device, float bounds_min[3], float bounds_max[3], rt_scene **out) {
+    if (!out || (n_meshes && !meshes)) return rt_internal_set_error(RT_EINVAL, "null argument");
+    *out = nullptr;
+    if (depth_limit > RT_MAX_TREE_DEPTH) return rt_internal_set_error(RT_ELIMIT, "depth_limit beyond RT_MAX_TREE_DEPTH");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return rt_internal_set_error(RT_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n_dev) return rt_internal_set_error(RT_EINVAL, "device index out of range");
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return rt_internal_set_error(RT_ENODEVICE, "cannot select the HIP device");
+    float *verts = nullptr, *norms = nullptr;
+    size_t nv = 0;
+    std::vector<rt_host::Tri> all;
+    int rc = rt_host::merge_meshes(meshes, n_meshes, &verts, &norms, &nv, all);
+    // what rt_scene_create checks on the host arrays it is given (the device arrays the scene is made from here are not read back)
+    for (size_t i = 0; rc == RT_OK && i < all.size(); i++) {
+        if (all[i].a >= nv || all[i].b >= nv || all[i].c >= nv) rc = rt_internal_set_error(RT_ESCENE, "a triangle indexes a vertex that does not exist");
+        else if (all[i].material >= RT_NUM_MATERIALS) rc = rt_internal_set_error(RT_ESCENE, "a triangle's material id is out of range");
+    }
+    if (rc == RT_OK) {
+        const rt_host::Params P{depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps};
+        rt_octree info;
+        const int chosen = rt_internal_swap_device(device);      // the scene lives on the device that built it
+        rc = build_on_device(verts, norms, nv, all, P, &info, out);
+        (void)rt_internal_swap_device(chosen);
+        if (rc == RT_OK) {
+            for (int k = 0; k < 3; k++) { if (bounds_min) bounds_min[k] = info.bounds_min[k]; if (bounds_max) bounds_max[k] = info.bounds_max[k]; }
+        }
+    }
+    free(verts); free(norms);
     (void)hipSetDevice(prev);
     return rc;
 }

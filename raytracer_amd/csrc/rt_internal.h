@@ -184,4 +184,5 @@ int rt_scene_create_from(const float *vertices, const float *normals, size_t n_v
 int rt_skybox_set_from(rt_scene *scene, const uint8_t *const faces[6], int w, int h, int source_is_device);
 int rt_internal_set_error(int code, const char *msg);
 int rt_scene_device(const rt_scene *scene);
+int rt_internal_swap_device(int device);   // sets this thread's rt_set_device choice (-1: none) and returns the previous one
 }

@@ -112,13 +112,30 @@ private:
 // attachment (Framebuffer.cpp:6); depth is optional.
 class RayTracePass {
 public:
-    explicit RayTracePass(const Octree &octree) {
+    explicit RayTracePass(const Octree &octree) : m_min(octree.GetMinBounds()), m_max(octree.GetMaxBounds()) {
         const vec3 lo = octree.GetMinBounds(), hi = octree.GetMaxBounds();
         const float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
         check(rt_scene_create(octree.m_vertecies.empty() ? nullptr : &octree.m_vertecies[0].x, octree.m_normals.empty() ? nullptr : &octree.m_normals[0].x, octree.m_vertecies.size(),
                               octree.m_compressed_triangles.empty() ? nullptr : &octree.m_compressed_triangles[0].x, octree.m_compressed_triangles.size(),
                               octree.m_compressed_node_buffer.data(), octree.m_compressed_node_buffer.size(), bmin, bmax, &m_scene));
     }
+    // Octree::Octree and the buffer uploads (App.cpp:22-26) in one step that stays on GPU `device`: no host copy of the octree exists.
+    RayTracePass(const std::vector<Mesh> &meshes, size_t depth_limit, size_t max_triangles_per_node, size_t max_triangles_per_leaf, size_t keep_triangles_after_this_many_overlaps,
+                 int device) {
+        std::vector<rt_mesh> in(meshes.size());
+        for (size_t i = 0; i < meshes.size(); i++) {
+            const Mesh &m = meshes[i];
+            in[i].vertices = const_cast<float *>(m.m_vertecies.empty() ? nullptr : &m.m_vertecies[0].x);
+            in[i].normals = const_cast<float *>(m.m_normals.empty() ? nullptr : &m.m_normals[0].x);
+            in[i].triangles = const_cast<uint32_t *>(m.m_triangles.empty() ? nullptr : &m.m_triangles[0].x);
+            in[i].n_vert = m.m_vertecies.size(); in[i].n_tri = m.m_triangles.size();
+        }
+        float lo[3], hi[3];
+        check(rt_scene_create_from_meshes(in.data(), in.size(), depth_limit, max_triangles_per_node, max_triangles_per_leaf, keep_triangles_after_this_many_overlaps, device, lo, hi, &m_scene));
+        m_min = {lo[0], lo[1], lo[2]}; m_max = {hi[0], hi[1], hi[2]};
+    }
+    vec3 GetMinBounds() const { return m_min; }    // (of the octree, when the pass was made from meshes)
+    vec3 GetMaxBounds() const { return m_max; }
     ~RayTracePass() { (void)rt_scene_destroy(m_scene); }
     RayTracePass(const RayTracePass &) = delete;
     RayTracePass &operator=(const RayTracePass &) = delete;
@@ -163,6 +180,7 @@ private:
         return t;
     }
     rt_scene *m_scene = nullptr;
+    vec3 m_min{}, m_max{};
     uint32_t m_still_frame_counter = 1;            // App.cpp:29
 };
 

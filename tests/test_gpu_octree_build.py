@@ -1,5 +1,6 @@
 """The device octree builder (rt_octree_build_device) against the host builder and the reference's digests: the
 flattened arrays must be identical word for word."""
+import ctypes
 import hashlib
 import json
 import os
@@ -99,3 +100,46 @@ def test_flat_mesh_and_huge_triangle():
     huge = api.Mesh(positions=np.array([[-50, -50, 0], [50, -50, 0], [0, 80, 0]], np.float32), faces=np.array([[0, 1, 2]], np.uint32), material_id=2)
     for meshes in ([flat], [flat, huge]):
         same(api.Octree(meshes, 12, 10, 6, 6), api.Octree(meshes, 12, 10, 6, 6, device=0))
+
+
+def test_scene_straight_from_meshes_renders_what_the_two_steps_render():
+    """rt_scene_create_from_meshes (build on the device, scene from the arrays where they are) against Octree + Scene: same
+    bounds, same records, same pixels and the same work counted, in all three pipelines."""
+    from raytracer_amd.camera import Camera
+    from raytracer_amd.params import Uniforms
+    meshes = [scenes.bunny_mesh()] + scenes.synthetic_primitives(40, seed=9, sphere_subdiv=1, extent=1.2, centre=(0.0, 1.5, 0.0), size_range=(0.1, 0.3), materials=(0, 2, 5))
+    oc = api.Octree(meshes, 12, 10, 6, 6)
+    sky = np.random.default_rng(3).integers(0, 256, size=(6, 16, 16, 4), dtype=np.uint8)
+    two = api.Scene.from_octree(oc, device=0); two.set_skybox(sky)
+    one = api.Scene.from_meshes(meshes, 12, 10, 6, 6, device=0); one.set_skybox(sky)
+    assert np.array_equal(one.bounds_min.view(np.uint32), oc.GetMinBounds().view(np.uint32))
+    assert np.array_equal(one.bounds_max.view(np.uint32), oc.GetMaxBounds().view(np.uint32))
+    def info(sc):      # node records, deepest level, references, face-coplanar triangles
+        out = (ctypes.c_uint32 * 4)()
+        assert api.lib().rt_internal_scene_info(sc._h, out) == api.RT_OK
+        return tuple(out)
+    assert info(one) == info(two)
+    u = Uniforms.from_camera(Camera(aspect=160 / 96), max_recursion_limit=4).pack()
+    for pipe in ("megakernel", "wavefront", "persistent"):
+        outs = []
+        for sc in (one, two):
+            sc.set_pipeline(pipe); sc.set_counting(True)
+            g = sc.render(u, 160, 96)
+            outs.append((g, sc.stats()))
+        (a, sa), (b, sb) = outs
+        for k in ("kind", "slot", "nrays"):
+            assert np.array_equal(a[k], b[k]), (pipe, k)
+        for k in ("t", "depth", "rgba"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (pipe, k)
+        assert sa == sb, pipe
+    one.close(); two.close()
+
+
+def test_scene_from_meshes_refuses_what_scene_create_refuses():
+    bad = scenes.bunny_mesh()
+    bad.m_triangles = bad.m_triangles.copy()
+    bad.m_triangles[5, 3] = 9          # no such material
+    with pytest.raises(api.RtError):
+        api.Scene.from_meshes([bad], device=0)
+    empty = api.Scene.from_meshes([], device=0)      # no mesh at all: a scene of spheres, like rt_scene_create with empty arrays
+    empty.close()

@@ -191,7 +191,7 @@ def test_scene_beyond_a_24_bit_record_index(test_sky):
     meshes = scenes.synthetic_primitives(4000, seed=9, sphere_subdiv=3, extent=3.0, size_range=(0.15, 0.4), materials=(1, 5, 6, 2), perturb=0.01, boxes=False)
     oc = api.Octree(meshes, 18, 10, 6, 6, device=0)
     sc = api.Scene.from_octree(oc, device=0)
-    info = (C.c_uint32 * 3)()
+    info = (C.c_uint32 * 4)()
     assert api.lib().rt_internal_scene_info(sc._h, info) == api.RT_OK
     assert info[0] > (1 << 24) and info[2] == len(oc.m_compressed_triangles) > 30_000_000
     sc.set_skybox(test_sky)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the host octree builder against the device builder on the bench scenes and checks that the arrays agree."""
+"""Times the host octree builder against the device builder on the bench scenes and checks that the arrays agree; and the way from
+meshes to a device-resident scene in two steps (builder, rt_scene_create) against rt_scene_create_from_meshes."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,5 +17,9 @@ for name, (make, params) in cases.items():
     t0 = time.perf_counter(); host = api.Octree(meshes, *params); t1 = time.perf_counter()
     dev = api.Octree(meshes, *params, device=0); t2 = time.perf_counter()
     dev = api.Octree(meshes, *params, device=0); t3 = time.perf_counter()
+    t4 = time.perf_counter(); two = api.Scene.from_octree(dev, device=0); t5 = time.perf_counter(); two.close()
+    one = api.Scene.from_meshes(meshes, *params, device=0); t6 = time.perf_counter(); one.close()
+    t6b = time.perf_counter(); one = api.Scene.from_meshes(meshes, *params, device=0); t7 = time.perf_counter(); one.close()
+    print(f"{name}: to a scene on the device: build + create {t3 - t2 + t5 - t4:.3f} s, in one call without leaving the device {t7 - t6b:.3f} s", flush=True)
     ok = all(np.array_equal(host.as_dict()[k].view(np.uint32), dev.as_dict()[k].view(np.uint32)) for k in host.as_dict())
     print(f"{name}: host {t1 - t0:.3f} s, device {t3 - t2:.3f} s (first call {t2 - t1:.3f} s), identical={ok}, refs={len(host.m_compressed_triangles)}, words={len(host.m_compressed_node_buffer)}", flush=True)
