@@ -366,12 +366,20 @@ def main():
         total_bytes = traversal_bytes(local_tot) if pipeline == "wavefront" else frame_bytes(local_tot, px_local * steps, blended=True)
         abytes = total_bytes / max(k_launches, 1)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        pmc = counter_digest(workload_key(scene_name, W, H, limit, traversal), kernel) if world == 1 else None
+        pmc = counter_digest(workload_key(scene_name, W, H, limit, traversal), kernel)
         if pmc and not all(k in pmc for k in ("kernel_ms", "valu_issue_frac", "wait_frac")):
             pmc = None      # (a kernel the profiled run of this workload did not launch)
+        if pmc and world > 1:
+            # the counters were collected on one GPU; with the frame split over several the same kernel runs on a part of it: only the
+            # verdict on what bounds the kernel is carried over, not the per-launch figures
+            verdict_only, pmc = pmc, None
+        else:
+            verdict_only = None
         # What limits the kernel is read from the counters of this workload when they have been collected; the achieved
         # figure itself is the prescribed one: algorithmic bytes of the reference's data layout over the measured duration.
         bound = "hbm"
+        if verdict_only:
+            bound = verdict_only.get("bound_one_gpu", "unprofiled") + " (verdict of the one-GPU profile of this workload; counters are not collected per rank)"
         if pmc:
             hbm_frac = pmc["hbm_bytes_per_launch"] / (pmc["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             cands = {"hbm": hbm_frac, "valu-issue": pmc["valu_issue_frac"]}

@@ -69,6 +69,8 @@ for k, cs in pmc.items():
         d["wait_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
     if m.get("TCC_HIT_sum") is not None and (m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)) > 0:
         d["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+    if bench.get("roofline", {}).get("kernel") == base:
+        d["bound_one_gpu"] = bench["roofline"]["bound"]      # what bench.py concluded from these counters (carried over to its multi-GPU lines)
     total = lambda e: e.get("kernel_ms", 0.0) * e.get("kernel_calls", 0)
     if base not in digest or total(d) >= total(digest[base]):     # several instantiations of one kernel: the one most of the time goes to
         digest[base] = d
