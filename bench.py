@@ -379,7 +379,8 @@ def main():
         # figure itself is the prescribed one: algorithmic bytes of the reference's data layout over the measured duration.
         bound = "hbm"
         if verdict_only:
-            bound = verdict_only.get("bound_one_gpu", "unprofiled") + " (verdict of the one-GPU profile of this workload; counters are not collected per rank)"
+            bound = (verdict_only["bound_one_gpu"] + " (verdict of the one-GPU profile of this workload; counters are not collected per rank)" if "bound_one_gpu" in verdict_only
+                     else f"unprofiled ({kernel} is not the kernel the one-GPU profile of this workload is about)")
         if pmc:
             hbm_frac = pmc["hbm_bytes_per_launch"] / (pmc["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             cands = {"hbm": hbm_frac, "valu-issue": pmc["valu_issue_frac"]}
