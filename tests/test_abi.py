@@ -58,6 +58,9 @@ def test_no_cpu_fallback():
     with pytest.raises(api.RtError) as e:
         api.Scene(np.zeros((0, 4)), np.zeros((0, 4)), np.zeros((0, 4)), np.zeros(0), z, z)
     assert e.value.code == api.RT_ENODEVICE
+    with pytest.raises(api.RtError) as e:      # the device builder behind it has no host stand-in either
+        api.Scene.from_meshes([], device=0)
+    assert e.value.code == api.RT_ENODEVICE
 
 
 def test_one_hip_runtime_in_the_process():
