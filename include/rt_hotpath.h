@@ -112,6 +112,9 @@ typedef struct rt_stats {
 
 /* Library / device ------------------------------------------------------------------------------------------ */
 const char *rt_last_error(void);
+/* First 16 hex digits of the SHA-256 over the sources of the render kernels and their host side (rt_kernels.hip, rt_internal.h,
+ * rt_api.cpp, concatenated in that order) as they were when the library was built: ties a measurement to the code it was taken on. */
+const char *rt_build_id(void);
 int rt_device_count(int *count);
 int rt_set_device(int device);     /* device used by subsequent rt_scene_create calls of this thread */
 
@@ -153,7 +156,10 @@ int rt_render_sequence(rt_scene *scene, const rt_frame *frames, size_t n_frames,
  *   - the array (1 MiB) is held by every GPU the library has created a scene on until the process ends, is shared by
  *     ALL scenes and calls on that GPU and keeps the last call's contents (the library clears what must start at zero):
  *     calls that overlap in time on one GPU race -- issue them on one stream, or order them yourself;
- *   - the first call of a process on a device loads the kernels' code: make one call before starting a capture. */
+ *   - the first call of a process on a device loads the kernels' code: make one call before starting a capture;
+ *   - a call made while its stream is being captured does not touch the array at all (its tiles start in index order instead of
+ *     the measured-cost order, pixels unchanged), so a replayed graph cannot meet an order another call left there; it also
+ *     returns without waiting whatever `sync` says, since the work only runs when the graph is launched. */
 #define RT_NOALLOC_MAX_TILES (1u << 17)
 int rt_render_noalloc(rt_scene *scene, const rt_frame *frame, const rt_target *target);
 /* Number of rows a compact band buffer holds for this frame's band selection (whole strips; the last strip may
@@ -196,8 +202,12 @@ int rt_scene_set_subframes(rt_scene *scene, int n);
  * 0 (default): chosen from the size of the launch; 1: never. */
 int rt_scene_set_sequence_batch(rt_scene *scene, int max_frames);
 /* Order in which the children of an octree node are visited (no counterpart in the reference, whose order is fixed).
- * RT_ORDER_REFERENCE (default): the shader's own -- passing children in descending octant order whatever the ray's
- * direction (frag:489-513) -- with which every output is bit-identical to the shader's.
+ * RT_ORDER_AUTO (default): every output bit-identical to the shader's, by whichever of RT_ORDER_REFERENCE and
+ * RT_ORDER_NEAR_FIRST_EXACT the scene measures to be faster for the pipeline at hand -- it times them on its own frames like
+ * it times the pipelines (rt_scene_selection_state).  While work counters are on (rt_scene_set_counting) the automatic order is
+ * the reference's, whose work the counters are defined as.
+ * RT_ORDER_REFERENCE: the shader's own -- passing children in descending octant order whatever the ray's
+ * direction (frag:489-513) -- with which every output is bit-identical to the shader's by construction.
  * RT_ORDER_NEAR_FIRST: the children on the ray's near side first.  Closer hits are found earlier, later box tests reject
  * more (5 % fewer node visits on the reference's scene, 60 % on a scene of 1.6 M triangles) and frames get faster.  The
  * closest hit is searched over a different set of nodes, so a result can differ from the shader's where floating-point
@@ -206,15 +216,30 @@ int rt_scene_set_sequence_batch(rt_scene *scene, int max_frames);
  * This mode is held to the tolerance bar -- colour within 1/255 on at least 99.9 % of the pixels -- not to bit identity.
  * RT_ORDER_NEAR_FIRST_EXACT: the children nearest first AND the reference's result: among the references of the hit triangle
  * the one the shader's traversal meets first is reported (every node carries its rank in the shader's visiting order), and a
- * ray for which that cannot be decided locally -- an earlier reference of the triangle lies in a box the ray enters behind the
- * hit point, or another triangle is hit at the bit-equal distance -- is traversed again in the shader's own order.  Every
- * bit-exactness test of this repository also runs in this mode; what it does not cover by construction is a ray whose float
- * box and triangle tests disagree about a hit exactly on a box face (see the kernels' comment).  Wavefront and persistent
- * pipelines; the one-kernel pipeline runs the reference's order in this mode. */
+ * ray for which that cannot be decided locally is traversed again in the shader's own order.  That is the case when an earlier
+ * reference of the triangle lies in a box the ray enters behind the hit point; when another triangle is hit at the same
+ * distance or within 2^-18 of it; when a box is entered within 2^-18 of the closest distance known at that moment, so that
+ * rounding could have turned the pruning decision the other way; and when the ray hits a triangle lying in a face plane of the
+ * boxes around it.  What this does not cover by construction is a hit from a box that the ray enters MORE than that band
+ * behind the hit point while the box containing the hit point does not list the triangle (a ray grazing a box face along
+ * which the float triangle/box test of the build and the ray's slab test disagree): see the kernels' comment.  Every
+ * bit-exactness test of this repository also runs in this mode.  Wavefront and persistent pipelines; the one-kernel pipeline
+ * runs the reference's order in this mode (its waves' rays are coherent and most of them never enter the octree: near first
+ * saves it 5 % of its node visits on the reference's scene, and on deep scenes the wave-wide pipelines are 2-3x faster anyway). */
 #define RT_ORDER_REFERENCE 0
 #define RT_ORDER_NEAR_FIRST 1
 #define RT_ORDER_NEAR_FIRST_EXACT 2
+#define RT_ORDER_AUTO 3
 int rt_scene_set_traversal_order(rt_scene *scene, int order);
+/* What automatic selection has measured and would run next: pipeline (RT_PIPELINE_*), child order (RT_ORDER_REFERENCE or
+ * RT_ORDER_NEAR_FIRST_EXACT under RT_ORDER_AUTO, else the order that was set, as far as that pipeline has it) and the per-frame
+ * milliseconds of the five candidates: one-kernel; wavefront and persistent in the reference's order; wavefront and persistent in
+ * the exact near-first order (negative: not measured, or not a candidate under the scene's settings). */
+int rt_scene_selection_state(rt_scene *scene, int *pipeline, int *order, double ms_per_frame[5]);
+/* Pipeline and child order the LAST render call of this scene actually ran with (RT_EINVAL before the first one): the
+ * order reads RT_ORDER_REFERENCE where RT_ORDER_NEAR_FIRST_EXACT was asked for and the reference's order ran instead (the
+ * one-kernel pipeline; a scene with more than 32 face-coplanar triangles). */
+int rt_scene_last_mode(rt_scene *scene, int *pipeline, int *order);
 int rt_scene_destroy(rt_scene *scene);
 
 /* Host-side scene build: mirrors of the reference's Mesh and Octree classes --------------------------------- */

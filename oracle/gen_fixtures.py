@@ -204,6 +204,15 @@ SCENE_VIEWS = {
     "suzanne_metal": dict(scene="suzanne2", cam=Camera(eye=(-4.6, 2.4, 5.9), at=(-2.5, 1.25, 4.1), aspect=1.0), size=(128, 128)),
     # a tree 26 levels deep (the reference's own limit is 18): the traversal stacks of the deep-tree kernels
     "deep": dict(scene="deep", cam=Camera(eye=(0.9, 4.2, 0.8), at=(0.0, 3.6, 0.0), fovy=0.8, aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=6)),
+    # scenes.plane_aligned_scene: sheet vertices, edges and corners exactly on the octree's cell planes.  An oblique view; then views
+    # whose eye sits ON cell planes and looks along an axis with no lens blur, at ODD frame sizes (the rasteriser's interpolated NDC
+    # is captured and stored as for ref_ndc_*.npz), so that the centre row and column of rays run inside cell planes, through sheet
+    # edges and vertices; one eye is a lattice point inside the root box.
+    "planes_oblique": dict(scene="planes", cam=Camera(eye=(6.5, 7.0, 5.5), at=(0.0, 3.5, 0.0), aspect=1.0), size=(256, 256), kw=dict(max_recursion_limit=5)),
+    "planes_axis_z": dict(scene="planes", cam=Camera(eye=(0.0, 3.5, -7.0), at=(0.0, 3.5, 0.0), fovy=1.0, aspect=1.0), size=(257, 257), kw=dict(max_recursion_limit=4, blur_amount=0.0)),
+    "planes_axis_x": dict(scene="planes", cam=Camera(eye=(6.5, 4.0, 0.5), at=(0.0, 4.0, 0.5), fovy=0.9, aspect=255.0 / 129.0), size=(255, 129), kw=dict(max_recursion_limit=4, blur_amount=0.0)),
+    "planes_down": dict(scene="planes", cam=Camera(eye=(0.5, 7.75, -0.5), at=(0.5, 0.0, -0.5), up=(0.0, 0.0, 1.0), fovy=1.1, aspect=1.0), size=(193, 193), kw=dict(max_recursion_limit=3, blur_amount=0.0)),
+    "planes_inside": dict(scene="planes", cam=Camera(eye=(0.0, 5.0, 0.0), at=(1.0, 4.0, 1.0), fovy=1.3, aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=5, blur_amount=0.0)),
 }
 
 
@@ -215,7 +224,7 @@ def scene_fixtures():
                  bounds_min=np.zeros(3, np.float32), bounds_max=np.zeros(3, np.float32))
     from raytracer_amd import scenes
     built = {"materials": materials_scene, "suzanne5": lambda: suzanne_scene(5), "suzanne2": lambda: suzanne_scene(2), "empty": lambda: empty,
-             "deep": lambda: scenes.deep_test_scene().as_dict()}
+             "deep": lambda: scenes.deep_test_scene().as_dict(), "planes": lambda: scenes.plane_aligned_scene().as_dict()}
     only = sys.argv[2:] if len(sys.argv) > 2 else None
     for name, v in SCENE_VIEWS.items():
         if only and name not in only:
@@ -225,6 +234,16 @@ def scene_fixtures():
         u = Uniforms.from_camera(v["cam"], **v.get("kw", {})).pack()
         rec = reference_record(scene, u, w, h, sky)
         rec.update({"scene_" + k: a for k, a in scene.items()})
+        if (w & (w - 1)) or (h & (h - 1)):       # not powers of two: the rasteriser's NDC differs from the closed form (see ndc_fixture)
+            nx, ny = capture_ndc(w, h)
+            cx, cy = closed_form_ndc(w, h)
+            dx, dy = ulp_delta(nx, cx), ulp_delta(ny, cy)
+            # (the centre pixel of an odd size has the closed form 0 and an interpolated value of about 1e-8: a distance of
+            # hundreds of millions of representable floats, hence 32 bits)
+            assert np.abs(dx).max() < 2 ** 31 and np.abs(dy).max() < 2 ** 31
+            assert np.array_equal(apply_ulp_delta(cx, dx).view(np.uint32), nx.view(np.uint32)) and np.array_equal(apply_ulp_delta(cy, dy).view(np.uint32), ny.view(np.uint32))
+            rec["ndc_dx"], rec["ndc_dy"] = dx.astype(np.int32), dy.astype(np.int32)
+            print(name, "centre column ndc x:", nx[h // 2, w // 2], "centre row ndc y:", ny[h // 2, w // 2])
         np.savez_compressed(os.path.join(GOLDEN, f"refscene_{name}.npz"), **rec)
         tri = rec["kind"] == 2
         print(name, w, h, "kinds", np.bincount(rec["kind"].ravel(), minlength=6), "materials of primary triangle hits", np.unique(np.asarray(scene["tri_refs"]).reshape(-1, 4)[rec["slot"][tri], 3]).tolist(),

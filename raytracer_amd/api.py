@@ -28,8 +28,8 @@ RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = range(6)
 
 EXPORTED_SYMBOLS = [
-    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_render_noalloc", "rt_band_row_count", "rt_scene_stats",
-    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free", "rt_scene_create_from_meshes",
+    "rt_last_error", "rt_build_id", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_render_noalloc", "rt_band_row_count", "rt_scene_stats",
+    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_selection_state", "rt_scene_last_mode", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free", "rt_scene_create_from_meshes",
     # include/rt_camera.h (bound in glm_camera.py)
     "rt_vec3_normalize", "rt_camera_init", "rt_camera_set_view", "rt_camera_set_proj", "rt_camera_view_proj", "rt_camera_inv_view_proj", "rt_portal_difference_matrix", "rt_portal_ray",
     "rt_manipulator_init", "rt_manipulator_set_camera", "rt_manipulator_update", "rt_manipulator_key", "rt_manipulator_mouse_move", "rt_manipulator_mouse_wheel",
@@ -80,6 +80,10 @@ class rt_octree(C.Structure):
                 ("max_depth", C.c_size_t)]
 
 
+PIPELINE_NAMES = ["megakernel", "wavefront", "persistent", "auto"]
+ORDER_NAMES = ["reference", "near_first", "near_first_exact", "auto"]
+CANDIDATE_NAMES = ["megakernel", "wavefront", "persistent", "wavefront+near_first_exact", "persistent+near_first_exact"]
+
 _lib = None
 
 
@@ -98,6 +102,7 @@ def lib():
             import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.rt_last_error.restype = C.c_char_p
+        L.rt_build_id.restype = C.c_char_p
         L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.rt_set_device.argtypes = [C.c_int]
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -116,6 +121,8 @@ def lib():
         L.rt_scene_set_subframes.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_set_sequence_batch.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_set_traversal_order.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_selection_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.rt_scene_last_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_mesh_load_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
         L.rt_mesh_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(rt_mesh)]
@@ -133,6 +140,21 @@ def lib():
 def _check(rc: int):
     if rc != RT_OK:
         raise RtError(rc, lib().rt_last_error().decode(errors="replace"))
+
+
+def build_id() -> str:
+    """rt_build_id: digest of the kernel sources the loaded library was built from."""
+    return lib().rt_build_id().decode()
+
+
+def source_id() -> str:
+    """The same digest computed from the source files beside this package (equal to build_id() when the library is up to date)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("rt_kernels.hip", "rt_internal.h", "rt_api.cpp"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def device_count() -> int:
@@ -456,9 +478,22 @@ class Scene:
         _check(lib().rt_scene_set_sequence_batch(self._h, max_frames))
 
     def set_traversal_order(self, order: str):
-        """'reference' (default: the shader's own child order), 'near_first' (faster, held to the colour tolerance only) or
-        'near_first_exact' (near first, with the shader's result: see rt_hotpath.h)."""
-        _check(lib().rt_scene_set_traversal_order(self._h, {"reference": 0, "near_first": 1, "near_first_exact": 2}[order]))
+        """'auto' (default: bit-identical outputs by whichever of the next two the scene measures to be faster), 'reference' (the
+        shader's own child order), 'near_first_exact' (near first, with the shader's result: see rt_hotpath.h) or 'near_first'
+        (faster, held to the colour tolerance only)."""
+        _check(lib().rt_scene_set_traversal_order(self._h, ORDER_NAMES.index(order)))
+
+    def selection_state(self):
+        """(pipeline, order, {candidate: measured ms per frame or None}) of what automatic selection would run next."""
+        p, o, ms = C.c_int(), C.c_int(), (C.c_double * 5)()
+        _check(lib().rt_scene_selection_state(self._h, C.byref(p), C.byref(o), ms))
+        return PIPELINE_NAMES[p.value], ORDER_NAMES[o.value], {n: (ms[i] if ms[i] >= 0 else None) for i, n in enumerate(CANDIDATE_NAMES)}
+
+    def last_mode(self):
+        """(pipeline, order) the last render call actually ran with."""
+        p, o = C.c_int(), C.c_int()
+        _check(lib().rt_scene_last_mode(self._h, C.byref(p), C.byref(o)))
+        return PIPELINE_NAMES[p.value], ORDER_NAMES[o.value]
 
     def set_subframes(self, n: int):
         _check(lib().rt_scene_set_subframes(self._h, n))

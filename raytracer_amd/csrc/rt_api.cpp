@@ -68,6 +68,9 @@ int noalloc_setup(int dev) {
 }
 }  // namespace
 
+#define RT_N_CAND 5
+static const int kCandPipeline[RT_N_CAND] = {RT_PIPELINE_MEGAKERNEL, RT_PIPELINE_WAVEFRONT, RT_PIPELINE_PERSISTENT, RT_PIPELINE_WAVEFRONT, RT_PIPELINE_PERSISTENT};
+
 struct rt_scene {
     int device = 0;
     RtDeviceScene d{};
@@ -106,21 +109,23 @@ struct rt_scene {
     void *stage = nullptr;      // sample staging of batched sequence launches (RtBatch)
     size_t stage_elems = 0;
     int max_batch = 0;          // 0: automatic; 1: never batch
-    int order = RT_ORDER_REFERENCE;
-    // RT_PIPELINE_AUTO: the three pipelines give identical pixels, so the scene measures them on its own frames (event
-    // pairs around a call's launches, read back without blocking at a later call) and uses the fastest for the workload
-    // at hand; the others are measured again now and then.
+    int order = RT_ORDER_AUTO;
+    int last_pipeline = -1, last_order = -1;   // what the last render call ran with (rt_scene_last_mode)
+    // RT_PIPELINE_AUTO / RT_ORDER_AUTO: the three pipelines, and for the two wave-wide ones the reference's child order and the
+    // exact near-first order, give identical pixels, so the scene measures the candidates on its own frames (event pairs around
+    // a call's launches, read back without blocking at a later call) and uses the fastest for the workload at hand; the others
+    // are measured again now and then.  Candidate c: pipeline kCandPipeline[c], exact near-first order iff c >= 3.
     struct Tuner {
         // single frames and sequences are different workloads for the one-kernel pipeline (a sequence is traced several
         // frames per launch): each kind of call keeps measurements of its own, so that alternating between them loses none
         struct Table {
             uint64_t key = 0;                   // frame size / recursion limit / band split the measurements belong to
-            double ms[3] = {-1.0, -1.0, -1.0};  // per-frame time of each pipeline (< 0: not measured yet)
-            uint32_t seen[3] = {0, 0, 0};       // measurements taken (the first one of a pipeline is a warm-up and is dropped)
+            double ms[RT_N_CAND] = {-1.0, -1.0, -1.0, -1.0, -1.0};  // per-frame time of each candidate (< 0: not measured yet)
+            uint32_t seen[RT_N_CAND] = {0, 0, 0, 0, 0};             // measurements taken (the first one of a candidate is a warm-up and is dropped)
             uint32_t calls = 0;
         } tab[2];
         int cur = 0;                       // table of the call at hand (0: one frame, 1: a sequence)
-        int pending = -1;                  // pipeline of the measurement in flight
+        int pending = -1;                  // candidate of the measurement in flight
         int pending_tab = 0;
         uint32_t pending_frames = 0;
         bool look_again = false;            // the periodic second look at the slower pipelines is due
@@ -229,6 +234,10 @@ int upload(void **dst, const void *src, size_t bytes, bool from_device = false) 
 extern "C" {
 
 const char *rt_last_error(void) { return g_err; }
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char *rt_build_id(void) { return RT_BUILD_ID; }
 int rt_internal_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
 int rt_scene_device(const rt_scene *s) { return s ? s->device : -1; }
 
@@ -403,18 +412,65 @@ int rt_scene_set_pipeline(rt_scene *s, int pipeline) {
     return RT_OK;
 }
 
+// Which candidates (see rt_scene::Tuner) the scene's settings allow: a fixed pipeline or a fixed order narrows the choice; the
+// exact near-first order exists in the two wave-wide pipelines only, and not for a scene with too many face-coplanar triangles.
+static uint32_t candidate_mask(const rt_scene *s) {
+    uint32_t m = 0;
+    const bool exact_ok = s->d.n_risky != RT_RISKY_TOO_MANY && s->d.n_nodes != 0;
+    for (int c = 0; c < RT_N_CAND; c++) {
+        if (s->pipeline != RT_PIPELINE_AUTO && kCandPipeline[c] != s->pipeline) continue;
+        const bool exact = c >= 3;
+        // with counters on, the automatic order is the reference's: the counters are defined as the work of the shader's traversal
+        if (exact && (s->order != RT_ORDER_AUTO || !exact_ok || s->counting)) continue;
+        m |= 1u << c;
+    }
+    return m;
+}
+// Child order a candidate runs with under the scene's setting.
+static int candidate_order(const rt_scene *s, int c) {
+    if (s->order == RT_ORDER_AUTO) return c >= 3 ? RT_ORDER_NEAR_FIRST_EXACT : RT_ORDER_REFERENCE;
+    if (s->order == RT_ORDER_NEAR_FIRST_EXACT && (s->d.n_risky == RT_RISKY_TOO_MANY || kCandPipeline[c] == RT_PIPELINE_MEGAKERNEL)) return RT_ORDER_REFERENCE;
+    return s->order;
+}
+static int best_candidate(const rt_scene *s, const rt_scene::Tuner::Table &tb, uint32_t mask) {
+    int best = -1;
+    for (int c = 0; c < RT_N_CAND; c++) if ((mask >> c & 1u) && tb.ms[c] >= 0.0 && (best < 0 || tb.ms[c] < tb.ms[best])) best = c;
+    if (best < 0) for (int c = 0; c < RT_N_CAND; c++) if (mask >> c & 1u) { best = c; break; }
+    (void)s;
+    return best < 0 ? 0 : best;
+}
+
 int rt_scene_pipeline_state(rt_scene *s, int *selected, double ms_per_frame[3]) {
     if (!s || !selected || !ms_per_frame) return fail(RT_EINVAL, "null argument");
-    int best = -1;
     const rt_scene::Tuner::Table &tb = s->tuner.tab[s->tuner.cur];   // (of the kind of call made last)
-    for (int p = 0; p < 3; p++) { ms_per_frame[p] = tb.ms[p]; if (tb.ms[p] >= 0.0 && (best < 0 || tb.ms[p] < tb.ms[best])) best = p; }
-    *selected = s->pipeline != RT_PIPELINE_AUTO ? s->pipeline : (best >= 0 ? best : RT_PIPELINE_MEGAKERNEL);
+    for (int p = 0; p < 3; p++) ms_per_frame[p] = -1.0;
+    for (int c = 0; c < RT_N_CAND; c++) {
+        const int p = kCandPipeline[c];
+        if (tb.ms[c] >= 0.0 && (ms_per_frame[p] < 0.0 || tb.ms[c] < ms_per_frame[p])) ms_per_frame[p] = tb.ms[c];
+    }
+    *selected = kCandPipeline[best_candidate(s, tb, candidate_mask(s))];
+    return RT_OK;
+}
+
+int rt_scene_selection_state(rt_scene *s, int *pipeline, int *order, double ms_per_frame[5]) {
+    if (!s || !pipeline || !order || !ms_per_frame) return fail(RT_EINVAL, "null argument");
+    const rt_scene::Tuner::Table &tb = s->tuner.tab[s->tuner.cur];
+    for (int c = 0; c < RT_N_CAND; c++) ms_per_frame[c] = tb.ms[c];
+    const int c = best_candidate(s, tb, candidate_mask(s));
+    *pipeline = kCandPipeline[c]; *order = candidate_order(s, c);
+    return RT_OK;
+}
+
+int rt_scene_last_mode(rt_scene *s, int *pipeline, int *order) {
+    if (!s || !pipeline || !order) return fail(RT_EINVAL, "null argument");
+    if (s->last_pipeline < 0) return fail(RT_EINVAL, "the scene has not been rendered yet");
+    *pipeline = s->last_pipeline; *order = s->last_order;
     return RT_OK;
 }
 
 int rt_scene_set_traversal_order(rt_scene *s, int order) {
     if (!s) return fail(RT_EINVAL, "scene is null");
-    if (order != RT_ORDER_REFERENCE && order != RT_ORDER_NEAR_FIRST && order != RT_ORDER_NEAR_FIRST_EXACT) return fail(RT_EINVAL, "unknown traversal order %d", order);
+    if (order != RT_ORDER_REFERENCE && order != RT_ORDER_NEAR_FIRST && order != RT_ORDER_NEAR_FIRST_EXACT && order != RT_ORDER_AUTO) return fail(RT_EINVAL, "unknown traversal order %d", order);
     s->order = order;
     return RT_OK;
 }
@@ -504,11 +560,14 @@ static uint32_t band_rows_of(const rt_frame *f) {
 }
 uint32_t rt_band_row_count(const rt_frame *f) { return band_rows_of(f); }
 
-// RT_PIPELINE_AUTO: collects a finished measurement, then picks the pipeline of this call and says whether to time it.
-static int tuner_choose(rt_scene *s, uint64_t key, bool sequence, bool *measure) {
+// Automatic selection: collects a finished measurement, then picks the candidate of this call among those of `mask` and says
+// whether to time it.
+static int tuner_choose(rt_scene *s, uint64_t key, bool sequence, uint32_t mask, bool *measure) {
     rt_scene::Tuner &tn = s->tuner;
     *measure = false;
-    if (!tn.a && (hipEventCreate(&tn.a) != hipSuccess || hipEventCreate(&tn.b) != hipSuccess)) { tn.a = tn.b = nullptr; return RT_PIPELINE_MEGAKERNEL; }
+    int first = 0;
+    while (first < RT_N_CAND - 1 && !(mask >> first & 1u)) first++;
+    if (!tn.a && (hipEventCreate(&tn.a) != hipSuccess || hipEventCreate(&tn.b) != hipSuccess)) { tn.a = tn.b = nullptr; return first; }
     if (tn.pending >= 0 && hipEventQuery(tn.b) == hipSuccess) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, tn.a, tn.b) == hipSuccess && tn.pending_frames > 0) {
@@ -521,19 +580,23 @@ static int tuner_choose(rt_scene *s, uint64_t key, bool sequence, bool *measure)
     }
     tn.cur = sequence ? 1 : 0;
     rt_scene::Tuner::Table &t = tn.tab[tn.cur];
-    if (key != t.key) { t.key = key; for (int p = 0; p < 3; p++) { t.ms[p] = -1.0; t.seen[p] = 0; } t.calls = 0; if (tn.pending_tab == tn.cur) tn.pending = -1; }
+    if (key != t.key) { t.key = key; for (int p = 0; p < RT_N_CAND; p++) { t.ms[p] = -1.0; t.seen[p] = 0; } t.calls = 0; if (tn.pending_tab == tn.cur) tn.pending = -1; }
     t.calls++;
-    int best = -1;
-    for (int p = 0; p < 3; p++) if (t.ms[p] >= 0.0 && (best < 0 || t.ms[p] < t.ms[best])) best = p;
-    int choice = best >= 0 ? best : RT_PIPELINE_MEGAKERNEL;
+    int choice = best_candidate(s, t, mask);
     if (t.calls % 64u == 0u) tn.look_again = true;
     if (tn.pending < 0) {
         *measure = true;
         if (tn.no_explore) return choice;
-        for (int p = 0; p < 3; p++) if (t.ms[p] < 0.0) return p;                              // something still unknown: try it
+        for (int p = 0; p < RT_N_CAND; p++) if ((mask >> p & 1u) && t.ms[p] < 0.0) return p;   // something still unknown: try it
         if (tn.look_again) {                                                                   // look at the others again now and then
             tn.look_again = false;
-            choice = (best + 1 + (int)((t.calls / 64u) % 2u)) % 3;
+            int other = choice;
+            for (uint32_t k = 0, want = 1u + (t.calls / 64u) % (RT_N_CAND - 1u); k < want; ) {
+                other = (other + 1) % RT_N_CAND;
+                if (other == choice) break;
+                if (mask >> other & 1u) k++;
+            }
+            choice = other;
         }
     }
     return choice;
@@ -566,7 +629,9 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     // at 8K are 0.2 s): a long sequence is issued as a short probe part, which the selection may use to try a pipeline,
     // and the rest, which always runs on the best one known.
     const size_t probe_frames = (size_t)f->width * f->height >= ((size_t)1 << 23) ? 4 : 8;
-    if (s->pipeline == RT_PIPELINE_AUTO && !s->tuner.in_split && !s->counting && t->memory == RT_MEM_DEVICE && n_frames > probe_frames) {
+    const uint32_t cand_mask = candidate_mask(s);
+    const bool choosing = (cand_mask & (cand_mask - 1u)) != 0u;   // more than one candidate: the scene measures and selects
+    if (choosing && !s->tuner.in_split && !s->counting && t->memory == RT_MEM_DEVICE && n_frames > probe_frames) {
         rt_target head = *t;
         head.sync = 0;
         s->tuner.in_split = true;
@@ -587,6 +652,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         s->last_stream = st; s->used = true;
         return RT_OK;
     };
+    auto note_mode = [&](int pl, uint32_t near_first) { s->last_pipeline = pl; s->last_order = (pl == RT_PIPELINE_MEGAKERNEL && near_first == RT_ORDER_NEAR_FIRST_EXACT) ? RT_ORDER_REFERENCE : (int)near_first; };
 
     if (f->compact_rows > 1) return fail(RT_EINVAL, "compact_rows must be 0 or 1");
     RtLaunch L{};
@@ -595,18 +661,23 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
     L.n_local_rows = band_rows_of(f);   // rows owned by this part: whole strips, the last one clipped by the kernel
     L.compact_rows = f->compact_rows;
-    L.near_first = (s->order == RT_ORDER_NEAR_FIRST_EXACT && s->d.n_risky == RT_RISKY_TOO_MANY) ? 0u : (uint32_t)s->order;   // (see RtDeviceScene::risky_tris)
     L.n_cu = (uint32_t)s->n_cu;
     L.counters = s->counting ? s->d_counters : nullptr;
     if (s->counting) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 128, st));
 
     L.sub_parts = 1; L.sub_part = 0;
-    int pipeline = s->pipeline;
     bool measure = false;
-    if (pipeline == RT_PIPELINE_AUTO) {
-        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^ (uint64_t)(s->order ? 4 : 0);
-        pipeline = tuner_choose(s, key + 1, n_frames > 1, &measure);
+    int cand = 0;
+    while (cand < RT_N_CAND - 1 && !(cand_mask >> cand & 1u)) cand++;
+    if (choosing) {
+        // (with the slot plane of the primary hit requested the exact order also resolves the reference's slot: another workload)
+        const uint64_t key = ((uint64_t)f->width << 40) ^ ((uint64_t)f->height << 20) ^ ((uint64_t)min_limit << 8) ^ ((uint64_t)f->band_parts << 4) ^ (uint64_t)(s->counting ? 1 : 0) ^
+                             ((uint64_t)s->order << 1) ^ (uint64_t)(t->hit_slot ? 8 : 0) ^ ((uint64_t)cand_mask << 56);
+        cand = tuner_choose(s, key + 1, n_frames > 1, cand_mask, &measure);
     }
+    int pipeline = kCandPipeline[cand];
+    const int order = candidate_order(s, cand);
+    L.near_first = (uint32_t)order;   // (RT_ORDER_NEAR_FIRST_EXACT in the one-kernel pipeline: that kernel runs the reference's order, see rt_hotpath.h)
     bool wavefront = pipeline == RT_PIPELINE_WAVEFRONT && min_limit >= 1 && L.n_local_rows > 0;
     bool persistent = pipeline == RT_PIPELINE_PERSISTENT && L.n_local_rows > 0;
     // a measurement belongs to the pipeline that actually runs every frame of the call: frames without any segment go
@@ -630,9 +701,10 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
                     // (about 112 bytes per pixel.)  Under automatic selection a pipeline that cannot get its workspace is
                     // given up for this workload instead of failing the render: the one-kernel pipeline needs none.
                     if (s->pipeline != RT_PIPELINE_AUTO) return wrc;
-                    s->tuner.tab[s->tuner.cur].ms[RT_PIPELINE_WAVEFRONT] = 1e30; s->tuner.tab[s->tuner.cur].seen[RT_PIPELINE_WAVEFRONT] = 2;
+                    for (int c = 0; c < RT_N_CAND; c++) if (kCandPipeline[c] == RT_PIPELINE_WAVEFRONT) { s->tuner.tab[s->tuner.cur].ms[c] = 1e30; s->tuner.tab[s->tuner.cur].seen[c] = 2; }
                     (void)hipGetLastError();   // (the failed allocation's error is handled here)
-                    wavefront = false; measure = false; pipeline = RT_PIPELINE_MEGAKERNEL; K = 1;
+                    wavefront = false; measure = false; pipeline = RT_PIPELINE_MEGAKERNEL; cand = 0; K = 1;
+                    L.near_first = (uint32_t)candidate_order(s, 0);
                     break;
                 }
             } else if (persistent && !s->sub[j].pool) {
@@ -761,7 +833,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         if (hipEventRecord(s->tuner.a, st) != hipSuccess) return 1;
         const int rc = launch_frames(L0, kerr);
         if (rc != 0 || hipEventRecord(s->tuner.b, st) != hipSuccess) return rc != 0 ? rc : 1;
-        s->tuner.pending = pipeline; s->tuner.pending_tab = s->tuner.cur; s->tuner.pending_frames = (uint32_t)n_frames;
+        s->tuner.pending = cand; s->tuner.pending_tab = s->tuner.cur; s->tuner.pending_frames = (uint32_t)n_frames;
         return 0;
     };
     const size_t px = (size_t)f->width * f->height;                                            // ndc planes
@@ -771,6 +843,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         L.ndc_x = f->ndc_x; L.ndc_y = f->ndc_y;
         L.color = t->color; L.depth = t->depth; L.hit_kind = t->hit_kind; L.hit_slot = t->hit_slot; L.hit_t = t->hit_t; L.n_rays = t->n_rays;
         if (launch_all(L, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
+        note_mode(wavefront ? RT_PIPELINE_WAVEFRONT : persistent ? RT_PIPELINE_PERSISTENT : RT_PIPELINE_MEGAKERNEL, L.near_first);
         if (int mrc = mark_use()) return mrc;
         if (t->sync) HIP_TRY(hipStreamSynchronize(st));
         return RT_OK;
@@ -802,6 +875,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     if (launch_all(L, &kerr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
     HIP_TRY(hipMemcpyAsync(t->color, s->s_color, tpx * 16, hipMemcpyDeviceToHost, st));
     for (Plane &p : planes) if (p.host) HIP_TRY(hipMemcpyAsync(p.host, p.dev, p.bytes, hipMemcpyDeviceToHost, st));
+    note_mode(wavefront ? RT_PIPELINE_WAVEFRONT : persistent ? RT_PIPELINE_PERSISTENT : RT_PIPELINE_MEGAKERNEL, L.near_first);
     if (int mrc = mark_use()) return mrc;
     HIP_TRY(hipStreamSynchronize(st));
     return RT_OK;
@@ -833,7 +907,13 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
     if (s->device >= kMaxDevices || !g_noalloc[s->device].ptr) { if (int nrc = noalloc_setup(s->device)) return nrc; }
     NoAllocState &na = g_noalloc[s->device];
     hipStream_t st = (hipStream_t)f->stream;
-    if (s->used && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_use, 0));
+    // Under stream capture the call becomes a graph node that is replayed later, any number of times, whatever other calls have
+    // done to the shared array in between: a captured launch therefore neither reads nor writes the array (tiles start in index
+    // order), and the scene's last-use event -- which orders work across streams outside a capture -- is left alone.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && s->used && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_use, 0));
 
     RtLaunch L{};
     L.u = f->u;
@@ -841,7 +921,7 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
     L.band_rows = f->band_rows; L.band_parts = f->band_parts; L.band_part = f->band_part;
     L.n_local_rows = n_local_rows;
     L.compact_rows = f->compact_rows;
-    L.near_first = (uint32_t)s->order;
+    L.near_first = s->order == RT_ORDER_NEAR_FIRST ? 1u : 0u;   // (the one-kernel pipeline has the reference's order and the plain near-first order)
     L.n_cu = (uint32_t)s->n_cu;
     L.sub_parts = 1; L.sub_part = 0;
     L.counters = s->counting ? s->d_counters : nullptr;
@@ -852,28 +932,36 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
     const bool any = octree_screen_rect(s->d, f->u, f->width, f->height, rect);
     hot_tiles(rect, any, f->band_rows, f->band_parts, L.hot);
     if (units != 0) {
-        // The array keeps what the last call on this device left, whichever scene that was for.  An order is a permutation
-        // of the tiles of ONE frame geometry: it is used only by a call with the same geometry, and a call with another one
-        // starts from zeroed costs and the index order.
-        const uint32_t geo[7] = {f->width, f->height, f->band_rows, f->band_parts, f->band_part, n_local_rows, f->compact_rows};
-        uint64_t h = 1469598103934665603ull;
-        for (size_t i = 0; i < sizeof geo; i++) { h ^= ((const unsigned char *)geo)[i]; h *= 1099511628211ull; }
-        if (h == 0) h = 1;
-        uint32_t *cost = na.ptr, *order = na.ptr + RT_NOALLOC_MAX_TILES;
-        const bool known = na.key == h;
-        if (!known) {
-            na.age = 0; na.key = 0;
-            HIP_TRY(hipMemsetAsync(cost, 0, units * sizeof(uint32_t), st));
-        }
-        L.cost = cost;
-        L.order = known ? order : nullptr;
-        L.order_next = (na.age % 8u == 0u) ? order : nullptr;
-        na.age++;
-        // (the key is set only once a launch that writes the order is enqueued: age 0 always does)
         const char *kerr = nullptr;
-        if (rt_launch_render(s->d, L, nullptr, nullptr, st, &kerr, nullptr, nullptr) != 0) { na.key = 0; return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?"); }
-        na.key = h;
+        if (capturing) {
+            if (rt_launch_render(s->d, L, nullptr, nullptr, st, &kerr, nullptr, nullptr) != 0) return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?");
+        } else {
+            // The array keeps what the last call on this device left, whichever scene that was for.  An order is a permutation
+            // of the tiles of ONE frame geometry: it is used only by a call with the same geometry, and a call with another one
+            // starts from zeroed costs and the index order.  (The bookkeeping is per device and guarded; the array's CONTENTS are
+            // only safe when the calls on a device do not overlap in time, as the header says.)
+            const uint32_t geo[7] = {f->width, f->height, f->band_rows, f->band_parts, f->band_part, n_local_rows, f->compact_rows};
+            uint64_t h = 1469598103934665603ull;
+            for (size_t i = 0; i < sizeof geo; i++) { h ^= ((const unsigned char *)geo)[i]; h *= 1099511628211ull; }
+            if (h == 0) h = 1;
+            std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+            uint32_t *cost = na.ptr, *order = na.ptr + RT_NOALLOC_MAX_TILES;
+            const bool known = na.key == h;
+            if (!known) {
+                na.age = 0; na.key = 0;
+                HIP_TRY(hipMemsetAsync(cost, 0, units * sizeof(uint32_t), st));
+            }
+            L.cost = cost;
+            L.order = known ? order : nullptr;
+            L.order_next = (na.age % 8u == 0u) ? order : nullptr;
+            na.age++;
+            // (the key is set only once a launch that writes the order is enqueued: age 0 always does)
+            if (rt_launch_render(s->d, L, nullptr, nullptr, st, &kerr, nullptr, nullptr) != 0) { na.key = 0; return fail(RT_ENODEVICE, "kernel launch failed: %s", kerr ? kerr : "?"); }
+            na.key = h;
+        }
     }
+    s->last_pipeline = RT_PIPELINE_MEGAKERNEL; s->last_order = (int)L.near_first;
+    if (capturing) return RT_OK;     // (sync = 1 cannot be honoured inside a capture: the work runs when the graph is launched)
     if (hipEventRecord(s->last_use, st) != hipSuccess) return fail(RT_ENODEVICE, "hipEventRecord failed");
     s->last_stream = st; s->used = true;
     if (t->sync) HIP_TRY(hipStreamSynchronize(st));

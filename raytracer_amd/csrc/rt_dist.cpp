@@ -24,6 +24,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -54,6 +55,7 @@ const Rccl *rccl() {
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
@@ -138,15 +140,24 @@ int rt_dist_destroy(rt_dist *d) {
     return RT_OK;
 }
 
-int rt_dist_scene_create(rt_dist *d, int root, const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
-                         const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], rt_scene **out) {
-    if (!d || !out) return fail(RT_EINVAL, "null argument");
-    *out = nullptr;
-    if (root < 0 || root >= d->world) return fail(RT_EINVAL, "root rank out of range");
-    const Rccl *R = rccl();
-    if (!R) return fail(RT_ENODEVICE, "RCCL (librccl.so.1) cannot be loaded");
-    DeviceGuard guard(d->device);
-    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select the HIP device");
+namespace {
+// The largest status code over all ranks (RT_OK = 0 is the smallest), so that every rank leaves a collective call with the same
+// verdict.  `word`: four bytes of device memory.
+int agree(const Rccl *R, rt_dist *d, void *word, int status, int *agreed) {
+    HIP_TRY(hipMemcpy(word, &status, sizeof status, hipMemcpyHostToDevice));
+    NCCL_TRY(R->AllReduce(word, word, 1, ncclInt, ncclMax, d->comm, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(agreed, word, sizeof status, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+struct ThreadDevice {      // this thread's rt_set_device choice, for the duration of a call
+    int prev;
+    explicit ThreadDevice(int dev) : prev(rt_internal_swap_device(dev)) {}
+    ~ThreadDevice() { (void)rt_internal_swap_device(prev); }
+};
+
+int scene_create_on_ranks(const Rccl *R, rt_dist *d, int root, const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
+                          const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], rt_scene **out) {
     const bool is_root = d->rank == root;
     // The root builds its scene first: that validates the arrays, and its verdict travels with the sizes so that every
     // rank returns the same code.
@@ -168,20 +179,44 @@ int rt_dist_scene_create(rt_dist *d, int root, const float *vertices, const floa
         if (is_root) return status;                       // (its message is the root's own)
         return fail(head.status, "the root rank could not create the scene (its rt_last_error says why)");
     }
-    // the four arrays, device to device
+    // the four arrays, device to device: every rank first says whether it has the memory, so that none waits in a broadcast for
+    // a rank that has given up
     const size_t bytes[4] = {(size_t)head.n_vert * 16, (size_t)head.n_vert * 16, (size_t)head.n_ref * 16, (size_t)head.n_words * 4};
     const void *src[4] = {vertices, normals, tri_refs, nodes};
     DevBuf buf[4];
-    for (int k = 0; k < 4; k++) {
-        HIP_TRY(buf[k].alloc(bytes[k]));
-        if (is_root && bytes[k]) HIP_TRY(hipMemcpy(buf[k].p, src[k], bytes[k], hipMemcpyHostToDevice));
-        if (bytes[k]) NCCL_TRY(R->Broadcast(buf[k].p, buf[k].p, bytes[k], ncclChar, root, d->comm, nullptr));
+    int local = RT_OK, all = RT_OK;
+    for (int k = 0; k < 4 && local == RT_OK; k++) {
+        hipError_t e = buf[k].alloc(bytes[k]);
+        if (e == hipSuccess && is_root && bytes[k]) e = hipMemcpy(buf[k].p, src[k], bytes[k], hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipGetLastError(); local = fail(e == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "staging the scene arrays: %s", hipGetErrorString(e)); }
     }
+    if (int rc = agree(R, d, dh.p, local, &all)) return rc;
+    if (all != RT_OK) return local != RT_OK ? local : fail(all, "another rank could not stage the scene arrays (its rt_last_error says why)");
+    for (int k = 0; k < 4; k++)
+        if (bytes[k]) NCCL_TRY(R->Broadcast(buf[k].p, buf[k].p, bytes[k], ncclChar, root, d->comm, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    if (is_root) return RT_OK;
-    if (rt_set_device(d->device) != RT_OK) return RT_ENODEVICE;
-    return rt_scene_create_from((const float *)buf[0].p, (const float *)buf[1].p, (size_t)head.n_vert, (const uint32_t *)buf[2].p, (size_t)head.n_ref,
-                                (const uint32_t *)buf[3].p, (size_t)head.n_words, head.lo, head.hi, 1, out);
+    if (!is_root)
+        local = rt_scene_create_from((const float *)buf[0].p, (const float *)buf[1].p, (size_t)head.n_vert, (const uint32_t *)buf[2].p, (size_t)head.n_ref,
+                                     (const uint32_t *)buf[3].p, (size_t)head.n_words, head.lo, head.hi, 1, out);
+    if (int rc = agree(R, d, dh.p, local, &all)) return rc;
+    if (all != RT_OK) return local != RT_OK ? local : fail(all, "another rank could not derive its scene records (its rt_last_error says why)");
+    return RT_OK;
+}
+}  // namespace
+
+int rt_dist_scene_create(rt_dist *d, int root, const float *vertices, const float *normals, size_t n_vert, const uint32_t *tri_refs, size_t n_ref,
+                         const uint32_t *nodes, size_t n_words, const float bounds_min[3], const float bounds_max[3], rt_scene **out) {
+    if (!d || !out) return fail(RT_EINVAL, "null argument");
+    *out = nullptr;
+    if (root < 0 || root >= d->world) return fail(RT_EINVAL, "root rank out of range");
+    const Rccl *R = rccl();
+    if (!R) return fail(RT_ENODEVICE, "RCCL (librccl.so.1) cannot be loaded");
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return fail(RT_ENODEVICE, "cannot select the HIP device");
+    ThreadDevice chosen(d->device);      // the scene lands on this communicator's device whatever rt_set_device said before; restored on return
+    const int rc = scene_create_on_ranks(R, d, root, vertices, normals, n_vert, tri_refs, n_ref, nodes, n_words, bounds_min, bounds_max, out);
+    if (rc != RT_OK && *out) { (void)rt_scene_destroy(*out); *out = nullptr; }    // (rt_scene_destroy leaves the error message alone)
+    return rc;
 }
 
 int rt_dist_skybox_set(rt_dist *d, int root, rt_scene *scene, const uint8_t *const faces[6], int w, int h) {
@@ -239,15 +274,19 @@ int rt_dist_gather_frame(rt_dist *d, int root, const rt_frame *f, const void *ba
     auto strip_rows = [&](uint32_t strip) { const uint32_t y0 = strip * f->band_rows; return y0 + f->band_rows <= f->height ? f->band_rows : f->height - y0; };
     // Strip s of the frame belongs to part s % parts and is that part's local strip s / parts.  Every strip travels as one
     // message straight to its rows of the root's frame; the root's own strips are one strided device copy.
+    // (an error inside the group must not leave it open: the first one is kept and the group is closed whatever happened)
     NCCL_TRY(R->GroupStart());
-    for (uint32_t s = 0; s < n_strips; s++) {
+    ncclResult_t first = ncclSuccess;
+    for (uint32_t s = 0; s < n_strips && first == ncclSuccess; s++) {
         const uint32_t part = s % parts, local = s / parts;
         const size_t bytes = (size_t)strip_rows(s) * row_bytes;
         if (part == (uint32_t)root) continue;
-        if (is_root) NCCL_TRY(R->Recv((char *)frame_plane + (size_t)s * strip_bytes, bytes, ncclChar, (int)part, d->comm, st));
-        else if (part == (uint32_t)d->rank) NCCL_TRY(R->Send((const char *)band + (size_t)local * strip_bytes, bytes, ncclChar, root, d->comm, st));
+        if (is_root) first = R->Recv((char *)frame_plane + (size_t)s * strip_bytes, bytes, ncclChar, (int)part, d->comm, st);
+        else if (part == (uint32_t)d->rank) first = R->Send((const char *)band + (size_t)local * strip_bytes, bytes, ncclChar, root, d->comm, st);
     }
-    NCCL_TRY(R->GroupEnd());
+    const ncclResult_t closed = R->GroupEnd();
+    if (first != ncclSuccess) return fail(RT_ENODEVICE, "ncclSend / ncclRecv of a strip: %s", R->GetErrorString(first));
+    if (closed != ncclSuccess) return fail(RT_ENODEVICE, "ncclGroupEnd: %s", R->GetErrorString(closed));
     if (is_root) {
         for (uint32_t s = (uint32_t)root; s < n_strips; s += parts)
             HIP_TRY(hipMemcpyAsync((char *)frame_plane + (size_t)s * strip_bytes, (const char *)band + (size_t)(s / parts) * strip_bytes, (size_t)strip_rows(s) * row_bytes, hipMemcpyDeviceToDevice, st));

@@ -420,11 +420,15 @@ DEVI float ray_triangle(const Ray &r, const TriData &d) {
     if (__builtin_fabsf(det) < 0.000000000000001f) return -1.0f;
     const float inv_det = rcp_ieee(det);
     const f3 tvec = r.pos - v1;
-    const float u = inv_det * dot3(tvec, pvec);
+    const float ua = dot3(tvec, pvec);
+    const float u = inv_det * ua;
     if (u < 0.0f || u > 1.0f) return -1.0f;
     const f3 qvec = cross3(tvec, e1);
-    const float v = inv_det * dot3(r.dir, qvec);
-    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float va = dot3(r.dir, qvec);
+    const float v = inv_det * va;
+    // u + v of frag:277 is a sum of two products with the common factor invDet, which the shader compiler the reference runs under
+    // factors out: invDet * (ua + va).  An ulp apart from u + v in a quarter of the cases, which decides hits on the triangle's third edge.
+    if (v < 0.0f || inv_det * (ua + va) > 1.0f) return -1.0f;
     return dot3(e2, qvec) * inv_det;
 }
 
@@ -462,14 +466,30 @@ typedef LevelStackT<256> LevelStack;
 // positions per axis (lo, mid, hi), so the reference's per-child (bound - origin) * inverse_direction products and
 // their min/max are computed once per plane pair and shared: every value is produced by the same operation on the same
 // operands as in the reference, only not recomputed.  Returns the existing children that pass as a bitmask over octants.
-// `inclusive`: a box entered exactly at the closest distance passes too (the exact near-first mode, see Exact): tmin <= closest
-// is tested as tmin < the next float above closest (closest is never negative or NaN here; an infinite tmin fails tmin < tmax).
-DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest, bool inclusive = false) {
-    if (inclusive && closest < __builtin_inff()) closest = closest < 0x1p-126f ? 0x1p-126f : u2f(f2u(closest) + 1u);
+// `near_tie` (exact near-first mode only, else null): set when the entry distance of any child box lies within `band` of the
+// closest distance on either side -- a pruning decision that rounding could have turned the other way, or one that the
+// reference's strict comparison and an inclusive one would make differently (see Exact).  Every child's entry distance is one
+// of the six per-axis values below, so those are what is compared.
+#ifndef EXACT_BAND
+#define EXACT_BAND 0x1p-18f
+#endif
+DEVI float exact_band(float closest) { return fmaxf(closest * EXACT_BAND, 0x1p-126f); }   // (infinite for an infinite distance: nothing is within it, see below)
+template <bool BAND = false>
+DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest, float band = 0.0f, bool *near_tie = nullptr) {
     const f3 tl = (lo - r.pos) * r.inv, tm = (mid - r.pos) * r.inv, th = (hi - r.pos) * r.inv;
     // lower half of an axis: box [lo, mid] -> t1 = tl, t2 = tm; upper half: box [mid, hi] -> t1 = tm, t2 = th
     const f3 near0 = F3(fminf(tl.x, tm.x), fminf(tl.y, tm.y), fminf(tl.z, tm.z)), far0 = F3(fmaxf(tl.x, tm.x), fmaxf(tl.y, tm.y), fmaxf(tl.z, tm.z));
     const f3 near1 = F3(fminf(tm.x, th.x), fminf(tm.y, th.y), fminf(tm.z, th.z)), far1 = F3(fmaxf(tm.x, th.x), fmaxf(tm.y, th.y), fmaxf(tm.z, th.z));
+    if (BAND) {
+        // Straight-line code on purpose (the caller passes a band of zero where the flag does not apply): a branch here would end the
+        // basic block between the products above and the minima / maxima below, and the compiler then re-canonicalises all eighteen
+        // products before using them (fourteen more instructions per visit).
+        // (NaN differences -- 0 * inf planes -- drop out of the minima; with an infinite closest distance every difference is
+        // infinite and not BELOW the infinite band)
+        const float d0 = fminf(fminf(__builtin_fabsf(near0.x - closest), __builtin_fabsf(near0.y - closest)), __builtin_fabsf(near0.z - closest));
+        const float d1 = fminf(fminf(__builtin_fabsf(near1.x - closest), __builtin_fabsf(near1.y - closest)), __builtin_fabsf(near1.z - closest));
+        *near_tie = *near_tie | (fminf(d0, d1) < band);
+    }
     uint32_t oct_pass = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -592,11 +612,25 @@ struct Walk {
 // child whose box is entered at tmin >= the closest distance known when its parent is visited (frag:456-513).  Its slot is
 // therefore the FIRST one, in its visiting order, among the references with the final distance t* in the nodes it visits.
 //
-//  1. Near-first pass.  Children in the order of the ray's direction, pruning with tmin <= closest (inclusive), accepting
-//     t < closest.  It visits every node entered at tmin <= t* -- which R visits too, as its closest distance stays above t*
-//     until it meets a reference with t* -- so it sees every reference with distance t* in those nodes.  Among the references
-//     of ONE triangle with equal t that it tests it keeps the one whose node has the lowest rank (RtNodeRec::rank: R's visiting
-//     order).  A DIFFERENT triangle at the bit-equal distance sets `tie`.
+// Both traversals can only find hits in the same set H: references held by nodes whose boxes -- and all their ancestors' -- pass
+// the part of the slab test that does not depend on the closest distance; box entry distances never decrease from a node to its
+// children (the same rounded operations on nested planes).  If the nearest hit of H has a holder that is entered no later than
+// the hit (tmin <= t for the node), then R and any other pruning order end with that distance: nothing can prune the chain of
+// boxes leading to it before it is found.
+//
+//  1. Near-first pass.  Children in the order of the ray's direction, pruning and accepting exactly like R (tmin < closest,
+//     t < closest).  Among the references of ONE triangle with equal t that it tests it keeps the one whose node has the lowest
+//     rank (RtNodeRec::rank: R's visiting order).  It raises `tie` -- and the ray is traversed again in R's order, step 3 -- when
+//       a. a DIFFERENT triangle is hit at the closest distance or within EXACT_BAND (relative) of it, on either side: R's
+//          order decides which of the two it keeps, and whether it prunes the box of the other;
+//       b. the box of a child is entered within the band of the closest distance, on either side: the comparison that prunes
+//          it can fall the other way in R, whose closest distance at that moment may be another one within the band, and a
+//          reference with the distance t* in a box entered exactly AT t* is met by neither traversal or by R only.
+//     A flag raised against a closest distance that is later improved by more than the band is dropped again.
+//     Together a. and b. cover every ray for which the premise above can fail by less than the band: the nearest hit lies up to
+//     EXACT_BAND in FRONT of every box that lists its triangle (a hit point on a box face where the build's float triangle/box
+//     test left the triangle out of the box the point is in, or where the slab test puts the entry an ulp behind the hit),
+//     and R reports something else only if another hit or its pruning comparison falls into that gap.
 //  2. Candidate check.  A reference can also give t* from a node entered BEHIND the hit point (tmin > t*: the triangle sticks
 //     out of that node's box towards the ray origin).  Whether R visits such a node depends on everything R has met before it.
 //     So the result is `uncertain` if the kept reference's own node is entered behind the hit, or if the ray passes through
@@ -610,24 +644,28 @@ struct Walk {
 // depth do not depend on it.  Step 2 therefore runs only for segments whose slot is written out (Exact::slot); all others
 // finish after step 1 unless `tie` is set.
 //
-// Step 1 relies on every triangle being referenced by the leaf that contains the hit point.  That does not hold for a triangle
-// lying exactly IN a face plane of the boxes around it (RtDeviceScene::risky_tris: e.g. the triangles on the faces of the root box,
-// whose bounds are the extreme vertices): in floating point the reference's triangle/box test lists it in some of those boxes
-// only, a ray can hit it before entering any node that holds it, and whether the reference finds that hit depends on its
-// visiting order.  A ray that hits one of these (few) triangles is therefore traversed in the reference's order from the start
-// (hits_risky); a scene with more than RT_MAX_RISKY of them does not use this mode at all.
+// A triangle lying exactly IN a face plane of the boxes around it (RtDeviceScene::risky_tris: e.g. the triangles on the faces of
+// the root box, whose bounds are the extreme vertices) is listed by the build's float test in some of those boxes only, and a ray
+// can hit it well before entering any node that holds it -- beyond any band.  A ray that hits one of these (few) triangles is
+// therefore traversed in the reference's order from the start (hits_risky); a scene with more than RT_MAX_RISKY of them does not
+// use this mode at all.
 //
-// When step 1 finds no triangle closer than the initial distance, R -- which visits a subset of step 1's nodes -- finds
-// none either.  What is NOT covered: a ray whose float box and triangle tests disagree about a hit exactly on a box face in
-// such a way that R and the near-first pass end with different closest distances; every parity test runs in this mode too.
+// When step 1 finds no triangle closer than the initial distance, R -- which prunes at least as much -- finds none either.
+// What is NOT covered by construction: a triangle that is not face-coplanar, hit MORE than the band in front of every box that
+// lists it (the box containing the hit point does not list it and the ray runs on along the face it lies against for longer
+// than the band before it enters one that does), with another hit inside that stretch.  The llvmpipe records of a scene built for
+// this (sheet edges and corners exactly on cell planes, rays inside cell planes: tests/golden/refscene_planes_*.npz) and the
+// randomised comparisons with the CPU restatement run in this mode.
 struct Exact {
     uint32_t best_rank;       // rank of the node that holds closest_tri
     uint32_t best_id;         // the triangle behind closest_tri (RtTriRec::dup_first)
     uint32_t post_q, post_end;// candidate positions still to be checked (step 2) while post_q < post_end
     float closest0;           // closest distance before the octree (for the fallback)
+    float closest_hi;         // the closest distance times (1 + EXACT_BAND): upper end of the band in which another triangle's distance is a near-tie
+    float band;               // exact_band(closest distance): half-width of the band around it in which a box entry is a near-tie
     bool nf, tie;             // near-first pass running (cleared for the fallback); another triangle at the bit-equal distance
     bool slot;                // the reference's SLOT is wanted (step 2), not only its distance and triangle
-    DEVI void begin(float c0, bool want_slot) { best_rank = 0; best_id = 0; post_q = post_end = 0; closest0 = c0; nf = true; tie = false; slot = want_slot; }
+    DEVI void begin(float c0, bool want_slot) { best_rank = 0; best_id = 0; post_q = post_end = 0; closest0 = c0; closest_hi = c0; band = exact_band(c0); nf = true; tie = false; slot = want_slot; }
 };
 DEVI bool hits_risky(const RtDeviceScene &S, const TopLevels *top, const Ray &r) {
     bool hit = false;
@@ -641,18 +679,26 @@ DEVI bool hits_risky(const RtDeviceScene &S, const TopLevels *top, const Ray &r)
     }
     return hit;
 }
-// EXACT: 0 = plain traversal; 1 = exact near-first for segments whose slot nobody observes (ties between different triangles only);
+// EXACT: 0 = plain traversal; 1 = exact near-first for segments whose slot nobody observes (the tie flag only);
 // 2 = the same with the rank bookkeeping that step 2 needs.  (Kept apart because the bookkeeping is not free: on the 1.28 M-triangle
 // frame the tie flag costs 0.85 ms of 17.4 and the ranks another 0.6.)
 template <int EXACT>
 DEVI void accept_hit(float t, uint32_t slot, uint32_t id, uint32_t node_rank, float &closest, uint32_t &closest_tri, bool &tri_hit, Exact &x) {
     if (t >= 0.0f && t < closest) {
+        if (EXACT) {
+            // a flag raised against the previous closest distance stays only if the new one is within the band of it; the triangle
+            // that gave the previous distance (another one: references of one triangle give the bit-equal distance) raises it too
+            const float t_hi = t * (1.0f + EXACT_BAND);
+            x.tie = closest <= t_hi && (x.tie || tri_hit);
+            x.closest_hi = t_hi;
+            x.band = exact_band(t);
+            x.best_id = id;
+        }
         closest = t; closest_tri = slot; tri_hit = true;
-        if (EXACT) { x.best_id = id; x.tie = false; }
         if (EXACT == 2) x.best_rank = node_rank;
-    } else if (EXACT && x.nf && tri_hit && t == closest) {
+    } else if (EXACT && tri_hit && t >= closest && t <= x.closest_hi && x.nf) {
         if (id != x.best_id) x.tie = true;
-        else if (EXACT == 2 && (node_rank < x.best_rank || (node_rank == x.best_rank && slot < closest_tri))) { closest_tri = slot; x.best_rank = node_rank; }
+        else if (EXACT == 2 && t == closest && (node_rank < x.best_rank || (node_rank == x.best_rank && slot < closest_tri))) { closest_tri = slot; x.best_rank = node_rank; }
     }
 }
 // Must be called by all lanes of a wave together; `active` marks the lanes with a live traversal and is cleared when a
@@ -708,7 +754,7 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
         }
         const bool nf_pass = EXACT && x.nf;
         if (w.node.child_mask != 0) {
-            uint32_t pass = child_pass_octants(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest, nf_pass);
+            uint32_t pass = child_pass_octants<EXACT != 0>(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest, nf_pass ? x.band : 0.0f, &x.tie);
             if (near_first) pass = permute_octants(pass, w.key);
             if (pass) st.push_level(w.node.first_child, pass);
             w.node.child_mask = 0;

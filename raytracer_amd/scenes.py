@@ -158,3 +158,44 @@ def deep_test_scene(depth_limit: int = 30, device: int | None = None) -> api.Oct
     """A tree deeper than the reference's default limit of 18 (deep_test_meshes), for the traversal kernels built for
     deep trees."""
     return api.Octree(deep_test_meshes(), depth_limit, 10, 6, 6, device=device)
+
+
+def plane_aligned_meshes(seed: int = 17):
+    """Meshes whose vertices, edges and corners sit EXACTLY on the cell planes of the octree that is built from them: three
+    sheets of slanted triangles over lattices with a spacing of 0.5 (every sheet vertex is a lattice point with coordinates that
+    are multiples of 0.25, so every sheet edge lies in a cell plane of two axes and every vertex in planes of all three), two
+    corner triangles that pin the root box to [-4, 4] x [0, 8] x [-4, 4] (cell planes at multiples of 8 / 2^depth: all exact in
+    binary32), and a seeded clutter of small triangles in general position for other hits nearby.  No triangle is parallel to a
+    coordinate plane.  The adversarial input for traversal orders other than the shader's: hits on box faces, edges and corners,
+    where the float triangle/box test of the build and the ray's slab tests are least likely to agree."""
+    def sheet(axis: int, origin, n_i: int, n_j: int, base: float):
+        # lattice (i, j) over the two other axes, the sheet's own coordinate = base + 0.25 * ((i + 2 j) % 4): the three corners of
+        # every triangle differ in it, so no triangle lies in a coordinate plane
+        a, b = [k for k in range(3) if k != axis]
+        pos = np.zeros((n_i + 1, n_j + 1, 3), np.float64)
+        ii, jj = np.meshgrid(np.arange(n_i + 1), np.arange(n_j + 1), indexing="ij")
+        pos[..., a] = origin[0] + 0.5 * ii
+        pos[..., b] = origin[1] + 0.5 * jj
+        pos[..., axis] = base + 0.25 * ((ii + 2 * jj) % 4)
+        idx = lambda i, j: i * (n_j + 1) + j
+        faces = []
+        for i in range(n_i):
+            for j in range(n_j):
+                faces += [[idx(i, j), idx(i + 1, j), idx(i, j + 1)], [idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)]]
+        return pos.reshape(-1, 3), np.array(faces, np.uint32)
+    rng = np.random.default_rng(seed)
+    meshes = []
+    for axis, origin, n_i, n_j, base, mat in ((1, (-3.0, -3.0), 12, 12, 3.0, 1), (0, (1.0, -3.0), 10, 12, 1.0, 5), (2, (-3.0, 1.0), 12, 10, -1.0, 2)):
+        p, f = sheet(axis, origin, n_i, n_j, base)
+        meshes.append(api.Mesh(positions=p.astype(np.float32), faces=f, material_id=mat))
+    corners = np.array([[-4.0, 0.0, -4.0], [-3.7, 0.3, -3.9], [-3.8, 0.1, -3.6], [4.0, 8.0, 4.0], [3.6, 7.9, 3.8], [3.9, 7.7, 3.7]], np.float32)
+    meshes.append(api.Mesh(positions=corners, faces=np.array([[0, 1, 2], [3, 4, 5]], np.uint32), material_id=6))
+    c = rng.uniform(-3.0, 3.0, size=(240, 3)) + np.array([0.0, 4.0, 0.0])
+    tri = c[:, None, :] + rng.normal(0.0, 0.18, size=(240, 3, 3))
+    meshes.append(api.Mesh(positions=tri.reshape(-1, 3).astype(np.float32), faces=np.arange(720, dtype=np.uint32).reshape(-1, 3), material_id=4))
+    return meshes
+
+
+def plane_aligned_scene(device: int | None = None) -> api.Octree:
+    """plane_aligned_meshes in a depth-9 octree with small leaves (at most 4 triangles), so that the lattice planes are cell faces."""
+    return api.Octree(plane_aligned_meshes(), 9, 10, 4, 6, device=device)

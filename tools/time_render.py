@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--pipelines", default="wavefront,megakernel")
     ap.add_argument("--subframes", default="4", help="comma list of sub-frame counts")
-    ap.add_argument("--order", default="reference", choices=["reference", "near_first", "near_first_exact"])
+    ap.add_argument("--order", default="reference", choices=["reference", "near_first", "near_first_exact", "auto"])
     ap.add_argument("--host", action="store_true", help="host-memory target: every frame is staged over PCIe")
     ap.add_argument("--sequence", action="store_true", help="issue the timed frames as one rt_render_sequence call")
     a = ap.parse_args()
@@ -58,7 +58,7 @@ def main():
             extra = ""
             if a.count:
                 sc.set_counting(True); run(0, True); st = sc.stats(); sc.set_counting(False)
-                extra = f" rays={st['rays']} Mrays/s={st['rays'] / ms / 1e3:.0f} pops={st['node_pops']} tri={st['triangle_tests']} box={st['child_box_tests']} enter={st['rays_entering_octree']}"
+                extra = f" rays={st['rays']} Mrays/s={st['rays'] / ms / 1e3:.0f} pops={st['node_pops']} tri={st['triangle_tests']} box={st['child_box_tests']} enter={st['rays_entering_octree']} fallbacks={st['exact_fallbacks']} mode={sc.last_mode()}"
             print(f"{name:8s} {pipe:10s} sub={sub} seq={int(a.sequence)} limit={lim} {W}x{H}: {ms:.3f} ms/frame{extra}", flush=True)
         sc.close()
 
