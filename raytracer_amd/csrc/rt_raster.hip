@@ -545,6 +545,8 @@ extern "C" int rt_overlay_draw_band(rt_overlay_mesh *m, const rt_overlay_pass *p
     RasterTri *slots = static_cast<RasterTri *>(m->slots.p);
     unsigned long long *keys = static_cast<unsigned long long *>(m->keys.p);
     const unsigned px_grid = (unsigned)((n_px + BLOCK - 1) / BLOCK < 256u * 16u ? (n_px + BLOCK - 1) / BLOCK : 256u * 16u);
+    if ((unsigned long long)pass->n_draws * m->n_vert >= (1ull << 32) || (unsigned long long)pass->n_draws * m->n_tri >= (1ull << 32))
+        return rt_internal_set_error(RT_ELIMIT, "rt_overlay_draw: draws x vertices (and draws x triangles) must stay below 2^32");
     const uint32_t n_v = pass->n_draws * m->n_vert, n_t = pass->n_draws * m->n_tri;
     vertex_kernel<<<(n_v + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(C, m->vertices, d_world, d_world_it, vs);
     uint32_t *big_list = static_cast<uint32_t *>(m->big_list.p);

@@ -121,6 +121,12 @@ __global__ __launch_bounds__(BLOCK) void slot_owner_kernel(const RtNodeRec *__re
 }
 // Lists the references of triangles that lie in a face plane of the node holding them (see RtDeviceScene::risky_tris): list[0] counts,
 // list[1 + k] are slots (as many as fit `cap`).  Runs while the leaves' box fields still hold their boxes.
+// out[k] = tris[list[k]]
+__global__ __launch_bounds__(BLOCK) void gather_records_kernel(const RtTriRec *__restrict__ tris, const uint32_t *__restrict__ list, uint32_t n, RtTriRec *__restrict__ out) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) out[k] = tris[list[k]];
+}
+
 __global__ __launch_bounds__(BLOCK) void risky_kernel(const RtNodeRec *__restrict__ recs, uint32_t n_nodes, uint32_t n_ref, const uint4 *__restrict__ refs, const float4 *__restrict__ vertices,
                                                       uint32_t *__restrict__ list, uint32_t cap) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
@@ -358,10 +364,16 @@ int rt_build_scene_records(const float *vertices, const float *normals, const ui
         if ((e = hipMemcpy(h.data(), list.p, (CAP + 1) * 4, hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
         if (h[0] > CAP) *n_risky = RT_RISKY_TOO_MANY;
         else if (h[0]) {
-            std::vector<RtTriRec> recs;
+            // the listed records are gathered into one buffer on the device and copied once (a copy per record costs tens of
+            // microseconds each, and a triangle is listed once per node that holds it in a face plane)
+            Buf gathered;
+            if ((e = gathered.alloc((size_t)h[0] * sizeof(RtTriRec))) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(gather_records_kernel, dim3(grid_for(h[0])), dim3(BLOCK), 0, nullptr, (const RtTriRec *)tris, (const uint32_t *)list.p + 1, h[0], (RtTriRec *)gathered.p);
+            if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+            std::vector<RtTriRec> all(h[0]), recs;
+            if ((e = hipMemcpy(all.data(), gathered.p, (size_t)h[0] * sizeof(RtTriRec), hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
             for (uint32_t k = 0; k < h[0] && *n_risky != RT_RISKY_TOO_MANY; k++) {
-                RtTriRec r;
-                if ((e = hipMemcpy(&r, tris + h[1 + k], sizeof r, hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+                const RtTriRec &r = all[k];
                 bool seen = false;
                 for (const RtTriRec &q : recs) seen = seen || q.dup_first == r.dup_first;
                 if (!seen) { if (recs.size() == RT_MAX_RISKY) *n_risky = RT_RISKY_TOO_MANY; else recs.push_back(r); }

@@ -28,7 +28,7 @@ MODES = ["persistent", "wavefront", "megakernel", "persistent+exact", "wavefront
 def set_mode(sc, mode):
     pipe, _, order = mode.partition("+")
     sc.set_pipeline(pipe)
-    sc.set_traversal_order("near_first_exact" if order == "exact" else "reference")
+    sc.set_traversal_order("near_first_exact" if order == "exact" else ("auto" if pipe == "auto" else "reference"))
 
 
 @pytest.fixture(scope="module", params=MODES)

@@ -26,7 +26,7 @@ PIPELINES = ["megakernel", "wavefront", "persistent", "wavefront+exact", "persis
 def set_mode(sc, mode):
     pipe, _, order = mode.partition("+")
     sc.set_pipeline(pipe)
-    sc.set_traversal_order("near_first_exact" if order == "exact" else "reference")
+    sc.set_traversal_order("near_first_exact" if order == "exact" else ("auto" if pipe == "auto" else "reference"))
 BUILDERS = {"100k": scenes.synthetic_100k, "1m": scenes.synthetic_1m}
 W, H = 3840, 2160
 
@@ -89,6 +89,56 @@ def test_hip_matches_llvmpipe_on_the_synthetic_scenes(synthetic, view):
         set_mode(sc, pipe)
         check(sc.render(z["uniforms"], w, h), z)
     set_mode(sc, "auto")
+
+
+def test_default_settings_try_every_candidate_and_stay_bit_exact(synthetic):
+    """A scene left at its defaults (pipeline and child order chosen by the library): while the selection tries its five candidates
+    -- three pipelines, the two wave-wide ones in the shader's child order and in the exact near-first order -- every frame equals
+    the reference shader's record, and the mode a call ran with can be read back."""
+    name, _, d, _ = synthetic
+    z = np.load(os.path.join(GOLDEN, f"refsynth_{name}_bench.npz"))
+    w, h = (int(v) for v in z["size"])
+    sc = api.Scene.from_dict(d, device=0)
+    sc.set_skybox(z["sky"])
+    seen = set()
+    for _ in range(14):
+        check(sc.render(z["uniforms"], w, h), z)
+        seen.add(sc.last_mode())
+    pipe, order, ms = sc.selection_state()
+    assert all(v is not None for v in ms.values()), ms
+    assert order in ("reference", "near_first_exact") and pipe in ("megakernel", "wavefront", "persistent")
+    assert {("megakernel", "reference"), ("wavefront", "reference"), ("wavefront", "near_first_exact"), ("persistent", "near_first_exact")} <= seen, seen
+    # with work counters on the automatic order is the shader's: the counters are defined as its traversal's work
+    sc.set_counting(True)
+    sc.render(z["uniforms"], w, h)
+    assert sc.last_mode()[1] == "reference"
+    sc.close()
+
+
+def test_default_settings_run_the_deep_scene_in_the_exact_order_at_4k(synthetic, test_sky):
+    """At the benchmark's frame size the selection settles on the wavefront pipeline in the exact near-first order (about twice as
+    fast as the shader's order there), and the accumulated frame equals the one rendered in the shader's own order bit for bit."""
+    import torch
+    name, _, d, _ = synthetic
+    sc = api.Scene.from_dict(d, device=0)
+    sc.set_skybox(test_sky)
+    us = [Uniforms.from_camera(Camera(aspect=W / H), time=k / 60.0, max_recursion_limit=5).pack() for k in range(4)]
+    frames = [api.make_frame(u, W, H, accum_index=k + 1) for k, u in enumerate(us)]
+    color = torch.zeros((H, W, 4), device="cuda")
+    tg = api.rt_target()
+    tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 1, color.data_ptr()
+    for _ in range(14):
+        sc.render_sequence_raw(frames, tg)
+    pipe, order, ms = sc.selection_state()
+    assert (pipe, order) == ("wavefront", "near_first_exact"), (pipe, order, ms)
+    sc.render_sequence_raw(frames, tg)
+    assert sc.last_mode() == ("wavefront", "near_first_exact")
+    got = color.clone()
+    sc.set_pipeline("wavefront"); sc.set_traversal_order("reference")
+    sc.render_sequence_raw(frames, tg)
+    assert sc.last_mode() == ("wavefront", "reference")
+    assert torch.equal(got.view(torch.int32), color.view(torch.int32))
+    sc.close()
 
 
 def test_4k_frames_of_the_synthetic_scenes_match_the_oracle_on_row_bands(synthetic, test_sky):

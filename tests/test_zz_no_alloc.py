@@ -136,3 +136,45 @@ def test_noalloc_rejects_what_it_cannot_do(bunny_octree):
     sc.render_raw(fr, tg)
     assert torch.equal(ref.view(torch.int32), band.view(torch.int32))
     sc.close()
+
+
+def test_noalloc_captured_call_replays_after_another_geometry_used_the_array(bunny_octree, test_sky):
+    """A call captured into a HIP graph is replayed after calls with OTHER frame geometries have rewritten the shared array's cost
+    map and start order: a captured call uses neither (its tiles start in index order), so every replay gives rt_render's frame."""
+    import torch
+    sc = api.Scene.from_octree(bunny_octree, device=0)
+    sc.set_skybox(test_sky)
+    sc.set_pipeline("megakernel")
+    w, h = 640, 368
+    u = Uniforms.from_camera(Camera(aspect=w / h), max_recursion_limit=3).pack()
+    # (first calls outside any capture: they load the kernels' code and leave an order for this geometry in the array)
+    warm, tg_warm = _targets(torch, w, h)
+    for _ in range(2):
+        sc.render_noalloc_raw(api.make_frame(u, w, h, stream=torch.cuda.current_stream().cuda_stream), tg_warm)
+    torch.cuda.synchronize()
+    got, tg = _targets(torch, w, h)
+    tg.sync = 0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        sc.render_noalloc_raw(api.make_frame(u, w, h, blend=False, stream=torch.cuda.current_stream().cuda_stream), tg)
+    # other geometries in between: a smaller frame twice (the second call sorts a new order into the array), a band of a larger one
+    for (ow, oh, band, compact) in ((320, 192, (16, 1, 0), False), (320, 192, (16, 1, 0), False), (1280, 720, (16, 2, 1), True)):
+        ou = Uniforms.from_camera(Camera(aspect=ow / oh), max_recursion_limit=2).pack()
+        fr = api.make_frame(ou, ow, oh, band=band, compact=compact, stream=torch.cuda.current_stream().cuda_stream)
+        other, tg_other = _targets(torch, ow, api.band_row_count(fr) if compact else oh)
+        sc.render_noalloc_raw(fr, tg_other)
+    torch.cuda.synchronize()
+    ref, tg_ref = _targets(torch, w, h)
+    sc.render_raw(api.make_frame(u, w, h, blend=False, stream=torch.cuda.current_stream().cuda_stream), tg_ref)
+    for _ in range(3):
+        for name, _, _ in PLANES:
+            got[name].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        _same(torch, ref, got, "replay")
+    assert int((got["hit_kind"] == api.HIT_TRIANGLE).sum()) > 0
+    # and an uncaptured call afterwards still works with the array (its bookkeeping was not touched by the capture)
+    again, tg_again = _targets(torch, w, h)
+    sc.render_noalloc_raw(api.make_frame(u, w, h, blend=False, stream=torch.cuda.current_stream().cuda_stream), tg_again)
+    _same(torch, ref, again, "after the replays")
+    sc.close()
