@@ -277,13 +277,14 @@ def main():
         def uniforms(step):
             return Uniforms.from_camera(cam, time=step / 60.0, max_recursion_limit=limit).pack()
 
-        fr0 = api.make_frame(uniforms(0), W, H, band=(BAND_ROWS, parts, rank), compact=parts > 1)
-        rows_local = api.band_row_count(fr0) if parts > 1 else H
-        rows_pad = rdist.padded_row_count(H, BAND_ROWS, parts) if parts > 1 else H
+        compact = parts > 1 or cabi      # (the library's own gather takes compact band buffers, also from a single rank)
+        fr0 = api.make_frame(uniforms(0), W, H, band=(BAND_ROWS, parts, rank), compact=compact)
+        rows_local = api.band_row_count(fr0) if compact else H
+        rows_pad = rdist.padded_row_count(H, BAND_ROWS, parts) if compact else H
         color = torch.zeros((rows_pad, W, 4), dtype=torch.float32, device=device)
 
         def frame_of(step, accum_index):
-            return api.make_frame(uniforms(step), W, H, accum_index=accum_index, blend=True, band=(BAND_ROWS, parts, rank), stream=stream, compact=parts > 1)
+            return api.make_frame(uniforms(step), W, H, accum_index=accum_index, blend=True, band=(BAND_ROWS, parts, rank), stream=stream, compact=compact)
 
         def target_of(sync=False):
             tg = api.rt_target()
@@ -415,7 +416,7 @@ def main():
         if pipeline == "megakernel" and k_launches < steps:
             kernel = "render_batch_kernel"   # the library traced several frames of the sequence per launch
         k_ms = k_total_ms / max(k_launches, 1)
-        px_local = W * min(rows_local, H) if parts > 1 else W * H
+        px_local = W * min(rows_local, H) if compact else W * H
         all_bytes = frame_bytes(local_tot, px_local * steps, blended=True)
         if pipeline == "wavefront":
             # several kernels per frame, sub-frames overlapping: the frame's algorithmic bytes over the frame's time
@@ -519,6 +520,8 @@ def main():
             cfg = ns.pop("config")
             ns.update({k: cfg[k] for k in ("scene", "pipeline", "traversal_order", "selected_by", "candidates_ms")})
             ns.pop("valu", None)
+            for k in ("peak", "unit", "algorithmic_bytes"):      # (as in the headline report; the line has to stay short)
+                ns["roofline"].pop(k, None)
             out[name] = ns
         for a, b in (("north_star", "north_star_reference_order"), ("config3", "config3_reference_order")):
             if a in out and b in out and out[a]["frame_crc32"] is not None:

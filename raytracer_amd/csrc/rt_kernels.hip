@@ -474,7 +474,13 @@ typedef LevelStackT<256> LevelStack;
 #define EXACT_BAND 0x1p-18f
 #endif
 DEVI float exact_band(float closest) { return fmaxf(closest * EXACT_BAND, 0x1p-126f); }   // (infinite for an infinite distance: nothing is within it, see below)
-template <bool BAND = false>
+// FOLD: the closest distance is folded into the far side of the z slab, so that a child costs two comparisons instead of three:
+// with m = min(tmax, closest), `tmax > 0 && tmin < tmax && tmin < closest` is `m > 0 && tmin < m` whenever closest > 0 (a NaN
+// plane drops out of either form alike).  With a closest distance of exactly 0 the folded form passes no child at all where the
+// reference still enters boxes around the ray's origin -- but nothing can be accepted after a hit at distance 0 (0 <= t < 0), so
+// the outcome of the traversal is the same; only the work counters and the bookkeeping of the exact near-first order would see
+// the difference, and those instantiations do not fold.
+template <bool BAND = false, bool FOLD = false>
 DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest, float band = 0.0f, bool *near_tie = nullptr) {
     const f3 tl = (lo - r.pos) * r.inv, tm = (mid - r.pos) * r.inv, th = (hi - r.pos) * r.inv;
     // lower half of an axis: box [lo, mid] -> t1 = tl, t2 = tm; upper half: box [mid, hi] -> t1 = tm, t2 = th
@@ -491,6 +497,17 @@ DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t ch
         *near_tie = *near_tie | (fminf(d0, d1) < band);
     }
     uint32_t oct_pass = 0;
+    if (FOLD) {
+        const float fz0 = fminf(far0.z, closest), fz1 = fminf(far1.z, closest);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float nx = (i & 1) ? near1.x : near0.x, ny = (i & 2) ? near1.y : near0.y, nz = (i & 4) ? near1.z : near0.z;
+            const float fx = (i & 1) ? far1.x : far0.x, fy = (i & 2) ? far1.y : far0.y, fz = (i & 4) ? fz1 : fz0;
+            const float tmin = fmaxf(fmaxf(nx, ny), nz), m = fminf(fminf(fx, fy), fz);
+            if (m > 0.0f && tmin < m) oct_pass |= 1u << i;
+        }
+        return oct_pass & child_mask;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const float nx = (i & 1) ? near1.x : near0.x, ny = (i & 2) ? near1.y : near0.y, nz = (i & 4) ? near1.z : near0.z;
@@ -587,7 +604,7 @@ DEVI void visit_node(const RtDeviceScene &S, const Ray &r, STACK &st, uint32_t k
         }
     }
     if (n.child_mask == 0) return;
-    uint32_t pass = child_pass_octants(r, n.lo, n.mid, n.hi, n.child_mask, closest);
+    uint32_t pass = child_pass_octants<false, !COUNT>(r, n.lo, n.mid, n.hi, n.child_mask, closest);
     if (near_first) pass = permute_octants(pass, key);      // (uniform branch)
     if (pass) st.push_level(n.first_child, pass);
 }
@@ -754,7 +771,9 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
         }
         const bool nf_pass = EXACT && x.nf;
         if (w.node.child_mask != 0) {
-            uint32_t pass = child_pass_octants<EXACT != 0>(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest, nf_pass ? x.band : 0.0f, &x.tie);
+            uint32_t pass = child_pass_octants<EXACT != 0, EXACT == 0 && !COUNT>(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest, nf_pass ? x.band : 0.0f, &x.tie);
+            // (the permutation as a 2 KB table in LDS -- one byte load instead of fifteen integer instructions -- measured 1.5 % faster on the
+            // 100 k-primitive frame and 5.6 % SLOWER on the 1.28 M-triangle one: the load sits in every visit's chain)
             if (near_first) pass = permute_octants(pass, w.key);
             if (pass) st.push_level(w.node.first_child, pass);
             w.node.child_mask = 0;
@@ -1027,21 +1046,22 @@ DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed 
     } else {
         const Material m = c_materials[h.material_id];
         const f3 mcol = F3(m.r, m.g, m.b);
+        // The three materials are written as one sequence instead of three separate branches: the random vector of the rough
+        // reflection / refraction (a cube root, a sine and a cosine) is drawn by metals, dielectrics and the specular case of the
+        // diffuse material alike, and lanes of different materials share one copy of that code instead of running three copies one
+        // after the other.  Per lane the operations and the order of the random draws are those of frag:604-657.
+        bool diffuse = false;
         if (m.type == LAMBERTIAN) {
             const float F = fresnel_schlick_roughness(fmaxf(-dot3(ray.dir, h.normal), 0.0f), 0.04f, m.roughness);
-            const bool diffuse = hash1(seed) > F;
+            diffuse = hash1(seed) > F;
             if (diffuse) color = color * mcol;
-            if (last) return;
-            ray.pos = h.position + h.normal * 0.001f;
-            if (diffuse) ray.dir = random_cos_weighted_hemisphere_direction(h.normal, seed);
-            else ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
         } else if (m.type == METAL) {
             color = color * mcol;
-            if (last) return;
-            ray.pos = h.position + h.normal * 0.001f;
-            ray.dir = normalize3(reflect3(ray.dir, h.normal) + random_in_unit_sphere(seed) * m.roughness);
-        } else {
-            if (last) return;       // a dielectric leaves the colour alone
+        }
+        if (last) return;       // (a dielectric leaves the colour alone)
+        f3 rough = F3(0.0f, 0.0f, 0.0f);
+        if (!diffuse) rough = random_in_unit_sphere(seed) * m.roughness;
+        if (m.type == DIELECTRIC) {
             float ri, cosine; f3 on;
             const float dn = dot3(ray.dir, h.normal);
             if (dn > 0.0f) {
@@ -1053,7 +1073,7 @@ DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed 
                 cosine = -dn;
                 on = h.normal;
             }
-            const f3 md = ray.dir + random_in_unit_sphere(seed) * m.roughness;
+            const f3 md = ray.dir + rough;
             const f3 refr = normalize3(refract3(md, on, ri));
             if (refr.x != 0.0f || refr.y != 0.0f || refr.z != 0.0f) {   // true for NaN (total internal reflection)
                 const float rr = div_ieee(1.0f - ri, 1.0f + ri);
@@ -1064,6 +1084,10 @@ DEVI void scatter(const rt_uniforms &U, const Hit &h, Ray &ray, f3 &color, Seed 
                 ray.pos = h.position - on * 0.001f;
                 ray.dir = normalize3(reflect3(md, on));
             }
+        } else {
+            ray.pos = h.position + h.normal * 0.001f;
+            if (diffuse) ray.dir = random_cos_weighted_hemisphere_direction(h.normal, seed);
+            else ray.dir = normalize3(reflect3(ray.dir, h.normal) + rough);
         }
     }
     seed.rebase();

@@ -13,11 +13,31 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def random_view(rng):
+def random_view(rng, lattice=False):
     from raytracer_amd.camera import Camera, Portals, normalize
     from raytracer_amd.params import Uniforms
+    if lattice and rng.uniform() < 0.5:
+        # the plane-aligned scene: the eye ON cell planes (coordinates that are multiples of 0.25), looking along an axis or at a
+        # lattice point, no lens blur -- rays that run inside cell planes and through sheet edges and corners
+        eye = np.round(rng.uniform((-7, 0.25, -7), (7, 7.75, 7)) * 4) / 4
+        axis = rng.integers(0, 3)
+        if rng.uniform() < 0.6:
+            at = eye.copy(); at[axis] += 1.0 if eye[axis] < 0 or axis == 1 and eye[axis] < 4 else -1.0
+        else:
+            at = np.round(rng.uniform((-3, 1, -3), (3, 7, 3)) * 4) / 4
+        if np.allclose(at, eye):
+            at = eye + (1.0, 0.0, 0.0)
+        up = (0.0, 0.0, 1.0) if abs(at[0] - eye[0]) + abs(at[2] - eye[2]) < 1e-9 else (0.0, 1.0, 0.0)
+        w, h = [(128, 128), (192, 64), (64, 160), (256, 128)][rng.integers(0, 4)]
+        cam = Camera(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), up=up, fovy=float(rng.choice([0.5, 1.0, 1.5, 2.0])), aspect=w / h)
+        u = Uniforms.from_camera(cam, time=float(rng.choice([0.0, rng.uniform(0, 100)])), max_recursion_limit=int(rng.integers(1, 7)), blur_amount=0.0)
+        return u.pack(), w, h
     kind = rng.integers(0, 4)
-    if kind == 0:      # orbiting the scene
+    if lattice:        # (the sheets fill [-3, 3] x [1, 7] x [-3, 3])
+        kind = 4
+        a, r = rng.uniform(0, 2 * np.pi), rng.uniform(0.0, 9.0)
+        eye = (r * np.cos(a), rng.uniform(0.2, 7.8), r * np.sin(a)); at = (rng.uniform(-2, 2), rng.uniform(2, 6), rng.uniform(-2, 2))
+    elif kind == 0:      # orbiting the scene
         a, r = rng.uniform(0, 2 * np.pi), rng.uniform(1.5, 9.0)
         eye = (r * np.cos(a), rng.uniform(0.2, 5.0), r * np.sin(a)); at = (rng.uniform(-1, 1), rng.uniform(0, 1.5), rng.uniform(-1, 1))
     elif kind == 1:    # among the small spheres
@@ -46,8 +66,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--near-first", action="store_true", help="also render with RT_ORDER_NEAR_FIRST and count the pixels whose colour differs from the oracle's (that mode is held to a tolerance, not to bit identity: differences are reported, not failures)")
     ap.add_argument("--ndc-table", action="store_true", help="hand both sides a per-pixel NDC table (the closed form moved by a few units in the last place, as a rasteriser's interpolation does) instead of the closed form")
-    ap.add_argument("--scene", default="bunny", choices=["bunny", "small", "s100k", "s1m", "deep"],
-                    help="small: a cluster of meshes carrying all seven materials on triangles; s100k / s1m: the seeded synthetic scenes of the benchmark; deep: a 26-level tree")
+    ap.add_argument("--scene", default="bunny", choices=["bunny", "small", "s100k", "s1m", "deep", "planes"],
+                    help="small: a cluster of meshes carrying all seven materials on triangles; s100k / s1m: the seeded synthetic scenes of the benchmark; deep: a 26-level tree; "
+                         "planes: sheets whose vertices, edges and corners lie exactly on the octree's cell planes, half of the views with the eye on cell planes too")
     ap.add_argument("--order", default="reference", choices=["reference", "near_first_exact"],
                     help="child order of the traversal for the bit-exact comparison: the shader's own, or nearest first with the shader's result "
                          "(every view is then also rendered without the debug planes, where that mode skips resolving the slot)")
@@ -55,7 +76,7 @@ def main():
     from oracle import oracle
     from raytracer_amd import api, scenes
     rng = np.random.default_rng(a.seed)
-    oc = {"bunny": scenes.default_octree, "small": scenes.small_test_scene, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "deep": scenes.deep_test_scene}[a.scene]()
+    oc = {"bunny": scenes.default_octree, "small": scenes.small_test_scene, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "deep": scenes.deep_test_scene, "planes": scenes.plane_aligned_scene}[a.scene]()
     sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
     osc = oracle.OracleScene(oc.as_dict(), sky)
     sc = api.Scene.from_octree(oc); sc.set_skybox(sky)
@@ -64,7 +85,7 @@ def main():
     bad = 0
     nf_pixels = nf_diff = nf_beyond = nf_slot = 0
     for v in range(a.views):
-        u, w, h = random_view(rng)
+        u, w, h = random_view(rng, lattice=a.scene == "planes")
         ndc = None
         if a.ndc_table:
             x = (np.float32(2.0) * (np.arange(w, dtype=np.float32) + np.float32(0.5)) / np.float32(w) - np.float32(1.0)).astype(np.float32)

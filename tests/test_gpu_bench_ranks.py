@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--steps", "3", "--warmup", "1", "--width", "640", "--height", "360", "--max-recursion-limit", "3", "--no-cpu-baseline", "--no-north-star"]
+COMMON = ["--steps", "3", "--warmup", "1", "--width", "640", "--height", "352", "--max-recursion-limit", "3", "--no-cpu-baseline", "--no-north-star"]
 
 
 def run_bench(extra, env_extra):
@@ -36,3 +36,26 @@ def test_two_rank_rehearsal_gathers_the_one_rank_frame(pipeline):
     assert one["rays_per_frame"] == two["rays_per_frame"]
     for rep in (one, two):
         assert rep["roofline"]["frac"] > 0 and rep["value"] > 0 and len(json.dumps(rep)) < 6000
+
+
+@pytest.mark.parametrize("dist_backend", ["torch", "cabi"])
+def test_single_rank_through_the_rccl_code_path(dist_backend):
+    """RT_BENCH_FORCE_DIST=1 under torch.distributed.run with one rank: the process group, the scene broadcast and the gather of the
+    accumulated frame run over RCCL (torch.distributed's, or the library's own calls of include/rt_dist.h), and the frame that comes
+    out of the gather is the frame of the plain single-process run."""
+    import socket
+    plain = run_bench(["--gpus", "1"], {})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"RT_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py")] + COMMON + ["--gpus", "1", "--dist", dist_backend]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rep = json.loads(lines[0])
+    assert rep["ranks"]["world_size"] == 1 and ("RCCL" in rep["ranks"]["backend"])
+    assert rep["frame_crc32"] == plain["frame_crc32"]

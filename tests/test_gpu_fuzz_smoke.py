@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
     ("fuzz_parity", ["--views", "30", "--seed", "5", "--order", "near_first_exact"]),
     ("fuzz_parity", ["--views", "20", "--seed", "6", "--scene", "s100k", "--order", "near_first_exact"]),
     ("fuzz_parity", ["--views", "12", "--seed", "7", "--scene", "deep", "--order", "near_first_exact", "--ndc-table"]),
+    ("fuzz_parity", ["--views", "30", "--seed", "8", "--scene", "planes", "--order", "near_first_exact"]),
     ("fuzz_sequences", ["--cases", "25", "--seed", "3"]),
     ("fuzz_octree", ["--cases", "25", "--seed", "3"]),
     ("fuzz_scene_validation", ["--cases", "300", "--seed", "3"]),

@@ -22,7 +22,7 @@ def same(a: api.Octree, b: api.Octree):
     assert a.max_depth == b.max_depth
 
 
-def test_bunny_matches_reference_digests():
+def test_bunny_matches_the_survey_digests():
     oc = api.Octree([scenes.bunny_mesh()], 18, 10, 6, 6, device=0)
     want = json.load(open(os.path.join(GOLDEN, "bunny_octree_digest.json")))
     d = oc.as_dict()

@@ -13,7 +13,9 @@ from raytracer_amd import api, scenes
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def test_bunny_matches_reference_digests(bunny_octree):
+def test_bunny_matches_the_survey_digests(bunny_octree):
+    """bunny_octree_digest.json holds the digests that a build of the reference's Octree.cpp against a stand-in for glm produced when
+    the reference was surveyed: a cross-check of the builders, not a pin by a reference build (glm is absent from the image)."""
     d = json.load(open(os.path.join(GOLDEN, "bunny_octree_digest.json")))
     o = bunny_octree
     for key, arr in (("vertices", o.m_vertecies), ("normals", o.m_normals), ("tri_refs", o.m_compressed_triangles), ("nodes", o.m_compressed_node_buffer)):
@@ -24,7 +26,7 @@ def test_bunny_matches_reference_digests(bunny_octree):
     assert (len(o.m_vertecies), len(o.m_compressed_triangles), len(o.m_compressed_node_buffer), o.max_depth) == (35947, 529434, 654908, 17)
 
 
-def test_oracle_builder_matches_reference_digests():
+def test_oracle_builder_matches_the_survey_digests():
     z = np.load(os.path.join(GOLDEN, "bunny_mesh.npz"))
     v, n, t = oracle.mesh_build(z["positions"], None, z["faces"], 1, np.diag([20.0, 20.0, 20.0, 1.0]).astype(np.float32))
     o = oracle.octree_build(v, t, 18, 10, 6, 6)

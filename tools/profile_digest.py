@@ -3,7 +3,7 @@
   <tag>_bench.json          the bench line
   <tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary (per-kernel calls / total / average ns)
   <tag>_pmc.json            mean counter value per kernel dispatch, per kernel
-  pmc_digest.json           per workload ("scene:WxH:limitN:order") and kernel: HBM bytes per launch and the derived figures
+  pmc_digest.json           per workload ("scene:WxH:limitN:order") and kernel (plus "_build_id": the library build they belong to): HBM bytes per launch and the derived figures
                             bench.py reports (roofline.traffic, roofline.counters); entries of other workloads are kept
 usage: tools/profile_digest.py <tag> [directory under gpurun_out/, default prof]"""
 import collections, csv, glob, json, os, shutil, sys
@@ -76,6 +76,7 @@ for k, cs in pmc.items():
         digest[base] = d
 path = os.path.join(dst, "pmc_digest.json")
 allw = json.load(open(path)) if os.path.exists(path) else {}
+digest["_build_id"] = bench.get("build_id")     # rt_build_id() of the library the counters were collected on: bench.py reports counters_stale when it differs
 allw[key] = digest
 json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
 print(key)
