@@ -474,12 +474,18 @@ typedef LevelStackT<256> LevelStack;
 #define EXACT_BAND 0x1p-18f
 #endif
 DEVI float exact_band(float closest) { return fmaxf(closest * EXACT_BAND, 0x1p-126f); }   // (infinite for an infinite distance: nothing is within it, see below)
-// FOLD: the closest distance is folded into the far side of the z slab, so that a child costs two comparisons instead of three:
+// max / min of three as ONE instruction.  Written as nested fmaxf / fminf the compiler shares the inner results between the eight
+// children of a node (four inner and eight outer operations per side instead of eight three-operand ones); same NaN rule as the
+// nested form (an operand that is NaN drops out).
+DEVI float max3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEVI float min3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// FOLD: the closest distance is folded into the far side of the z slab, so that a child costs ONE comparison instead of three:
 // with m = min(tmax, closest), `tmax > 0 && tmin < tmax && tmin < closest` is `m > 0 && tmin < m` whenever closest > 0 (a NaN
 // plane drops out of either form alike).  With a closest distance of exactly 0 the folded form passes no child at all where the
 // reference still enters boxes around the ray's origin -- but nothing can be accepted after a hit at distance 0 (0 <= t < 0), so
-// the outcome of the traversal is the same; only the work counters and the bookkeeping of the exact near-first order would see
-// the difference, and those instantiations do not fold.
+// the outcome of the traversal is the same; only the work counters would see the difference, and the counting instantiations do
+// not fold.  (The near-first pass of the exact order, which looks for other triangles at the closest distance, gives a ray with a
+// hit at distance 0 to the reference's order: accept_hit.)
 template <bool BAND = false, bool FOLD = false>
 DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t child_mask, float closest, float band = 0.0f, bool *near_tie = nullptr) {
     const f3 tl = (lo - r.pos) * r.inv, tm = (mid - r.pos) * r.inv, th = (hi - r.pos) * r.inv;
@@ -498,13 +504,15 @@ DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t ch
     }
     uint32_t oct_pass = 0;
     if (FOLD) {
+        // ... and 0 into the near side: max(tmin, 0) < m is `tmin < m && 0 < m`, one comparison per child.  (The rays that get here
+        // have passed the root box test, so they are not NaN rays; a NaN plane of one axis drops out of either form.)
         const float fz0 = fminf(far0.z, closest), fz1 = fminf(far1.z, closest);
+        const float nz0 = fmaxf(near0.z, 0.0f), nz1 = fmaxf(near1.z, 0.0f);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float nx = (i & 1) ? near1.x : near0.x, ny = (i & 2) ? near1.y : near0.y, nz = (i & 4) ? near1.z : near0.z;
+            const float nx = (i & 1) ? near1.x : near0.x, ny = (i & 2) ? near1.y : near0.y, nz = (i & 4) ? nz1 : nz0;
             const float fx = (i & 1) ? far1.x : far0.x, fy = (i & 2) ? far1.y : far0.y, fz = (i & 4) ? fz1 : fz0;
-            const float tmin = fmaxf(fmaxf(nx, ny), nz), m = fminf(fminf(fx, fy), fz);
-            if (m > 0.0f && tmin < m) oct_pass |= 1u << i;
+            if (max3f(nx, ny, nz) < min3f(fx, fy, fz)) oct_pass |= 1u << i;
         }
         return oct_pass & child_mask;
     }
@@ -512,7 +520,7 @@ DEVI uint32_t child_pass_octants(const Ray &r, f3 lo, f3 mid, f3 hi, uint32_t ch
     for (int i = 0; i < 8; i++) {
         const float nx = (i & 1) ? near1.x : near0.x, ny = (i & 2) ? near1.y : near0.y, nz = (i & 4) ? near1.z : near0.z;
         const float fx = (i & 1) ? far1.x : far0.x, fy = (i & 2) ? far1.y : far0.y, fz = (i & 4) ? far1.z : far0.z;
-        const float tmin = fmaxf(fmaxf(nx, ny), nz), tmax = fminf(fminf(fx, fy), fz);
+        const float tmin = max3f(nx, ny, nz), tmax = min3f(fx, fy, fz);
         if (tmax > 0.0f && tmin < tmax && tmin < closest) oct_pass |= 1u << i;
     }
     return oct_pass & child_mask;
@@ -705,8 +713,10 @@ DEVI void accept_hit(float t, uint32_t slot, uint32_t id, uint32_t node_rank, fl
         if (EXACT) {
             // a flag raised against the previous closest distance stays only if the new one is within the band of it; the triangle
             // that gave the previous distance (another one: references of one triangle give the bit-equal distance) raises it too
+            // (a hit at distance 0 exactly: references of other triangles at the same distance sit in boxes around the ray's origin, which
+            // the folded child test -- see child_pass_octants -- no longer enters: such a ray takes the reference's order)
             const float t_hi = t * (1.0f + EXACT_BAND);
-            x.tie = closest <= t_hi && (x.tie || tri_hit);
+            x.tie = (closest <= t_hi && (x.tie || tri_hit)) || t == 0.0f;
             x.closest_hi = t_hi;
             x.band = exact_band(t);
             x.best_id = id;
@@ -771,7 +781,7 @@ DEVI void walk_step(const RtDeviceScene &S, const TopLevels *top, const Ray &r, 
         }
         const bool nf_pass = EXACT && x.nf;
         if (w.node.child_mask != 0) {
-            uint32_t pass = child_pass_octants<EXACT != 0, EXACT == 0 && !COUNT>(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest, nf_pass ? x.band : 0.0f, &x.tie);
+            uint32_t pass = child_pass_octants<EXACT != 0, !COUNT>(r, w.node.lo, w.node.mid, w.node.hi, w.node.child_mask, closest, nf_pass ? x.band : 0.0f, &x.tie);
             // (the permutation as a 2 KB table in LDS -- one byte load instead of fifteen integer instructions -- measured 1.5 % faster on the
             // 100 k-primitive frame and 5.6 % SLOWER on the 1.28 M-triangle one: the load sits in every visit's chain)
             if (near_first) pass = permute_octants(pass, w.key);
