@@ -54,9 +54,25 @@ BAND_ROWS = 16
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak
 VALU_PEAK_TFLOPS_NO_FMA = 78.6  # 157.3 TFLOP/s fp32 vector peak counts an FMA as 2; this path may not fuse
 CPU_BASELINE_SECONDS = 12.0     # the CPU leg renders whole frames of the same workload until this much time has passed
-# The reference's own shader on Mesa llvmpipe, measured in the build container (the shader text does not travel to the
-# GPU box, so this leg cannot be re-run there): 3840x2160, bunny scene, steady-state frames, 8 threads.
-LLVMPIPE_REFERENCE = {2: {"ms_per_frame": [2836.0, 2936.0], "Mrays/s": [5.2, 5.4]}, 5: {"ms_per_frame": [3090.0, 3620.0], "Mrays/s": [4.7, 5.5]}}
+
+
+def llvmpipe_reference(scene: str, w: int, h: int, limit: int):
+    """The reference's own shader on Mesa llvmpipe for this workload, as measured in the build container on 8 threads when the
+    whole-frame fixtures were made (tests/golden/ref_fullframe_digests.json: best and mean of three steady-state frames; the
+    shader text does not travel to the GPU box, so this leg cannot be re-run there), or None."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "ref_fullframe_digests.json")) as f:
+            entries = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for e in entries.values():
+        lim = int(np.array(e["uniforms_bits"][19:20], np.uint32)[0])
+        if (e["scene"], e["width"], e["height"], lim) == (scene, w, h, limit):
+            ms = [e["llvmpipe"]["ms_best"], e["llvmpipe"]["ms_mean"]]
+            return {"ms_per_frame": [round(v, 1) for v in ms], "Mrays/s": [round(e["rays"] / v / 1e3, 2) for v in reversed(ms)], "cores": e["llvmpipe"]["threads"],
+                    "where": "build container, not this host (the shader text cannot travel)"}
+    return None
+
 SCENE_TEXT = {
     "bunny": "default scene (bundled Stanford bunny for the missing dragon, 69 451 triangles, Octree(18,10,6,6))",
     "synthetic_100k": "synthetic scene of 100 000 primitives (icospheres and boxes, 1.6 M triangles, seed 1, depth-8 octree)",
@@ -490,10 +506,9 @@ def main():
                     break
             rep["cpu_baseline"] = {"value": round(n_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                                    "sample": f"{n_frames} consecutive {W}x{H} frames of the same workload in {dt:.1f} s"}
-            ref = LLVMPIPE_REFERENCE.get(limit) if (scene_name, W, H) == ("bunny", 3840, 2160) else None
+            ref = llvmpipe_reference(scene_name, W, H, limit)
             if ref:
-                rep["cpu_baseline"]["reference_llvmpipe"] = {"Mrays/s": ref["Mrays/s"], "ms_per_frame": ref["ms_per_frame"], "cores": 8,
-                                                             "where": "build container, not this host (the shader text cannot travel)"}
+                rep["cpu_baseline"]["reference_llvmpipe"] = ref
         sc.close()
         del color
         return rep
@@ -520,6 +535,9 @@ def main():
             cfg = ns.pop("config")
             ns.update({k: cfg[k] for k in ("scene", "pipeline", "traversal_order", "selected_by", "candidates_ms")})
             ns.pop("valu", None)
+            ref = llvmpipe_reference(scene_name, W, H, 5)
+            if ref:      # (the same workload on the reference's own vehicle: frame times measured in the build container)
+                ns["reference_llvmpipe_ms_per_frame"] = ref["ms_per_frame"]
             for k in ("peak", "unit", "algorithmic_bytes"):      # (as in the headline report; the line has to stay short)
                 ns["roofline"].pop(k, None)
             out[name] = ns

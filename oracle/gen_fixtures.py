@@ -22,6 +22,10 @@ Fixtures
                           in a depth-8 octree; 1.28 M triangles in a depth-18 octree), stored WITHOUT the scene arrays: the
                           tests rebuild the scene from its seed and check the SHA-256 digests kept here
   refscene_deep.npz       a tree 26 levels deep (scenes.deep_test_scene), with its arrays
+  refscene_planes_*.npz   scenes.plane_aligned_scene (sheet vertices, edges and corners exactly on the octree's cell planes) from eyes on
+                          cell planes, at odd frame sizes with the rasteriser's NDC stored as ulp deltas
+  ref_fullframe_digests.json   SHA-256 digests of the reference's WHOLE frames at 1280x720 and 3840x2160 (bunny and both synthetic scenes)
+                          and llvmpipe's frame times for them
 """
 from __future__ import annotations
 
@@ -329,6 +333,53 @@ def sky_size_fixture():
     print("sky sizes", os.path.getsize(os.path.join(GOLDEN, "ref_sky_sizes.npz")))
 
 
+# Whole frames at the benchmark's sizes: too large to store (a 4K record is 200 MB), so their SHA-256 digests are kept instead.
+FULLFRAME = {
+    "bunny_720p_limit5": dict(scene="bunny", size=(1280, 720), kw=dict(max_recursion_limit=5)),
+    "bunny_4k_limit2": dict(scene="bunny", size=(3840, 2160), kw=dict(max_recursion_limit=2)),
+    "synthetic_100k_4k_limit5": dict(scene="synthetic_100k", size=(3840, 2160), kw=dict(max_recursion_limit=5)),
+    "synthetic_1m_4k_limit5": dict(scene="synthetic_1m", size=(3840, 2160), kw=dict(max_recursion_limit=5)),
+}
+
+
+def plane_digests(rec: dict) -> dict:
+    """SHA-256 of every plane of a record as the tests hash them: rgb / depth / t float32, slot uint32, kind / nrays uint8."""
+    out = {}
+    for k, dt in (("rgb", np.float32), ("depth", np.float32), ("t", np.float32), ("slot", np.uint32), ("kind", np.uint8), ("nrays", np.uint8)):
+        out[k] = hashlib.sha256(np.ascontiguousarray(rec[k], dt).tobytes()).hexdigest()
+    return out
+
+
+def fullframe_fixture():
+    """ref_fullframe_digests.json: the reference shader's WHOLE frames at 1280x720 and 3840x2160 -- the benchmark's camera on the
+    bunny scene and on the two seeded synthetic scenes -- as digests of every plane, with the uniforms (bit patterns), the scene's
+    digests and llvmpipe's frame time on this container's 8 threads (the CPU baseline of those workloads).  The rasteriser's
+    interpolated NDC at these sizes is the table of ref_ndc_<w>x<h>.npz (captured again here and checked against it)."""
+    import json
+    from raytracer_amd import scenes
+    sky = fixture_sky()
+    out = {}
+    built = {}
+    for name, v in FULLFRAME.items():
+        if v["scene"] not in built:
+            built[v["scene"]] = bunny_scene() if v["scene"] == "bunny" else {"synthetic_100k": scenes.synthetic_100k, "synthetic_1m": scenes.synthetic_1m}[v["scene"]]().as_dict()
+        scene = built[v["scene"]]
+        w, h = v["size"]
+        nx, ny = capture_ndc(w, h)
+        z = np.load(os.path.join(GOLDEN, f"ref_ndc_{w}x{h}.npz"))
+        cx, cy = closed_form_ndc(w, h)
+        assert np.array_equal(apply_ulp_delta(cx, z["ndc_dx"]).view(np.uint32), nx.view(np.uint32)) and np.array_equal(apply_ulp_delta(cy, z["ndc_dy"]).view(np.uint32), ny.view(np.uint32))
+        u = Uniforms.from_camera(Camera(aspect=w / h), **v["kw"]).pack()
+        rec = reference_record(scene, u, w, h, sky)
+        timing = json.loads(refrun.run_reference(scene, u, w, h, sky=sky, bench=3, threads=8)["stdout"].strip().splitlines()[-1])
+        out[name] = {"scene": v["scene"], "width": w, "height": h, "uniforms_bits": np.asarray(u, np.float32).view(np.uint32).tolist(),
+                     "sky": "oracle.gen_fixtures.fixture_sky()", "scene_sha256": scene_digests(scene), "sha256": plane_digests(rec),
+                     "kinds": np.bincount(rec["kind"].ravel(), minlength=6).tolist(), "rays": int(rec["nrays"].astype(np.int64).sum()),
+                     "llvmpipe": {"threads": 8, "ms_best": timing["ms_best"], "ms_mean": timing["ms_mean"], "where": "the build container (8 vCPU)"}}
+        print(name, out[name]["kinds"], out[name]["rays"], out[name]["llvmpipe"], flush=True)
+    json.dump(out, open(os.path.join(GOLDEN, "ref_fullframe_digests.json"), "w"), indent=1)
+
+
 def overlay_assets():
     """overlay_assets.npz: the mesh and texture of the reference's raster pass as its loaders hand them to GL (App.cpp:71-76):
     suzanne.obj through oracle.raster.load_obj, metal.png decoded to 8-bit RGBA and flipped (GLUtils.cpp:187-190)."""
@@ -472,6 +523,11 @@ def main():
         assert refrun.available(), "needs /root/reference and the llvmpipe runner"
         overlay_fixtures()
         present_fixture()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fullframe":
+        refrun.build()
+        assert refrun.available(), "needs /root/reference and the llvmpipe runner"
+        fullframe_fixture()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sky":
         refrun.build()

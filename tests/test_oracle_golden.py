@@ -229,3 +229,22 @@ def test_depth_attachment_fixture_coverage():
     seen = np.unique(np.concatenate([attachment_values(np.load(p)).ravel() for p in ATTACHMENT_FILES]))
     assert len(seen) > 100000 and seen.max() == 16777215 and seen.min() == 0 and (seen < 8388608).sum() > 2000      # depths below 0.5, where the float product rounds to halves
     assert np.array_equal(oracle.depth_attachment(np.array([-1.0, 0.0, 0.5, 1.0, 2.0, np.nan], np.float32)), [0, 0, 8388608, 16777215, 16777215, 0])
+
+
+@pytest.mark.parametrize("name", ["bunny_720p_limit5", "bunny_4k_limit2"])
+def test_oracle_matches_the_reference_whole_frame_digests(scene, name):
+    """The reference's WHOLE 1280x720 and 3840x2160 frames of the bunny scene, kept as SHA-256 digests of their planes
+    (ref_fullframe_digests.json): the restatement reproduces every one of them with the rasteriser's NDC table."""
+    import hashlib
+    import json
+    from oracle.gen_fixtures import fixture_sky
+    e = json.load(open(os.path.join(GOLDEN, "ref_fullframe_digests.json")))[name]
+    w, h = e["width"], e["height"]
+    z = np.load(os.path.join(GOLDEN, f"ref_ndc_{w}x{h}.npz"))
+    cx, cy = closed_form_ndc(w, h)
+    ndc = (apply_ulp_delta(cx, z["ndc_dx"]), apply_ulp_delta(cy, z["ndc_dy"]))
+    u = np.array(e["uniforms_bits"], np.uint32).view(np.float32)
+    o = oracle.OracleScene(scene, fixture_sky()).render(u, w, h, ndc=ndc)
+    for k, src, dt in (("rgb", o["rgba"][..., :3], np.float32), ("depth", o["depth"], np.float32), ("t", o["t"], np.float32), ("slot", o["slot"], np.uint32),
+                       ("kind", o["kind"], np.uint8), ("nrays", o["nrays"], np.uint8)):
+        assert hashlib.sha256(np.ascontiguousarray(src, dtype=dt).tobytes()).hexdigest() == e["sha256"][k], k
