@@ -17,7 +17,7 @@ Fixtures
                           on triangles, and the reference's quad mesh assets/suzanne.obj (as triangulated by oracle.parse_obj)
   ref_ndc_640x512.npz     the interpolated NDC varying at the reference's own window size (not a power of two, so it
                           differs from the closed form): int32 ulp deltas, plus reference taps/colour for a band of rows
-  ref_ndc_1280x720.npz, ref_ndc_3840x2160.npz   the same at the two benchmark frame sizes (int16 deltas, bands of rows)
+  ref_ndc_1280x720.npz, ref_ndc_3840x2160.npz, ref_ndc_7680x4320.npz   the same at the benchmark frame sizes (int16 deltas, bands of rows)
   refsynth_<scene>_<view>.npz   reference records of the seeded synthetic scenes of raytracer_amd/scenes.py (100 000 primitives
                           in a depth-8 octree; 1.28 M triangles in a depth-18 octree), stored WITHOUT the scene arrays: the
                           tests rebuild the scene from its seed and check the SHA-256 digests kept here
@@ -339,6 +339,7 @@ FULLFRAME = {
     "bunny_4k_limit2": dict(scene="bunny", size=(3840, 2160), kw=dict(max_recursion_limit=2)),
     "synthetic_100k_4k_limit5": dict(scene="synthetic_100k", size=(3840, 2160), kw=dict(max_recursion_limit=5)),
     "synthetic_1m_4k_limit5": dict(scene="synthetic_1m", size=(3840, 2160), kw=dict(max_recursion_limit=5)),
+    "bunny_8k_limit5": dict(scene="bunny", size=(7680, 4320), kw=dict(max_recursion_limit=5)),      # the camera-path workload's frame size
 }
 
 
@@ -350,17 +351,20 @@ def plane_digests(rec: dict) -> dict:
     return out
 
 
-def fullframe_fixture():
-    """ref_fullframe_digests.json: the reference shader's WHOLE frames at 1280x720 and 3840x2160 -- the benchmark's camera on the
+def fullframe_fixture(only=None):
+    """ref_fullframe_digests.json: the reference shader's WHOLE frames at 1280x720, 3840x2160 and 7680x4320 -- the benchmark's camera on the
     bunny scene and on the two seeded synthetic scenes -- as digests of every plane, with the uniforms (bit patterns), the scene's
     digests and llvmpipe's frame time on this container's 8 threads (the CPU baseline of those workloads).  The rasteriser's
     interpolated NDC at these sizes is the table of ref_ndc_<w>x<h>.npz (captured again here and checked against it)."""
     import json
     from raytracer_amd import scenes
     sky = fixture_sky()
-    out = {}
+    path = os.path.join(GOLDEN, "ref_fullframe_digests.json")
+    out = json.load(open(path)) if only and os.path.exists(path) else {}      # (named entries only: the others are kept)
     built = {}
     for name, v in FULLFRAME.items():
+        if only and name not in only:
+            continue
         if v["scene"] not in built:
             built[v["scene"]] = bunny_scene() if v["scene"] == "bunny" else {"synthetic_100k": scenes.synthetic_100k, "synthetic_1m": scenes.synthetic_1m}[v["scene"]]().as_dict()
         scene = built[v["scene"]]
@@ -377,7 +381,7 @@ def fullframe_fixture():
                      "kinds": np.bincount(rec["kind"].ravel(), minlength=6).tolist(), "rays": int(rec["nrays"].astype(np.int64).sum()),
                      "llvmpipe": {"threads": 8, "ms_best": timing["ms_best"], "ms_mean": timing["ms_mean"], "where": "the build container (8 vCPU)"}}
         print(name, out[name]["kinds"], out[name]["rays"], out[name]["llvmpipe"], flush=True)
-    json.dump(out, open(os.path.join(GOLDEN, "ref_fullframe_digests.json"), "w"), indent=1)
+    json.dump(out, open(path, "w"), indent=1)
 
 
 def overlay_assets():
@@ -515,8 +519,13 @@ def main():
         if sys.argv[1] == "synthetic":
             synthetic_fixtures()
         else:
-            ndc_fixture(1280, 720, (440, 504), max_recursion_limit=5)
-            ndc_fixture(3840, 2160, (1400, 1432), max_recursion_limit=2)
+            sizes = sys.argv[2:] or ["1280x720", "3840x2160", "7680x4320"]
+            if "1280x720" in sizes:
+                ndc_fixture(1280, 720, (440, 504), max_recursion_limit=5)
+            if "3840x2160" in sizes:
+                ndc_fixture(3840, 2160, (1400, 1432), max_recursion_limit=2)
+            if "7680x4320" in sizes:
+                ndc_fixture(7680, 4320, (2800, 2816), max_recursion_limit=5)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "overlay":
         refrun.build()
@@ -527,7 +536,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "fullframe":
         refrun.build()
         assert refrun.available(), "needs /root/reference and the llvmpipe runner"
-        fullframe_fixture()
+        fullframe_fixture(sys.argv[2:] or None)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sky":
         refrun.build()

@@ -1,8 +1,8 @@
 """Whole frames at the benchmark's sizes against the reference shader on llvmpipe: tests/golden/ref_fullframe_digests.json (made by
-`python -m oracle.gen_fixtures fullframe`) holds the SHA-256 of every plane of the reference's 1280x720 and 3840x2160 frames -- the
+`python -m oracle.gen_fixtures fullframe`) holds the SHA-256 of every plane of the reference's 1280x720, 3840x2160 and 7680x4320 frames -- the
 benchmark's camera on the bunny scene and on the two seeded synthetic scenes -- since the planes themselves are too large to keep.  The
 HIP pass renders the same frames with the rasteriser's interpolated NDC (ref_ndc_<w>x<h>.npz) and must reproduce every digest: primary
-hit kind, triangle slot, distance, segment count, depth and colour of all 0.9 / 8.3 million pixels, in the library's default mode and
+hit kind, triangle slot, distance, segment count, depth and colour of all 0.9 / 8.3 / 33.2 million pixels, in the library's default mode and
 with pipeline and child order pinned."""
 import hashlib
 import json

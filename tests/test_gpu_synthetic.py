@@ -202,9 +202,9 @@ def test_deep_tree_runs_the_deep_stack_kernels(test_sky):
     sc.close()
 
 
-@pytest.mark.parametrize("size", [(1280, 720), (3840, 2160)])
+@pytest.mark.parametrize("size", [(1280, 720), (3840, 2160), (7680, 4320)])
 def test_hip_matches_llvmpipe_at_the_benchmark_frame_sizes(bunny_octree, size):
-    """At 1280x720 and 3840x2160 the rasteriser's interpolated NDC is not the closed form (fp32 plane equations, the
+    """At 1280x720, 3840x2160 and 7680x4320 the rasteriser's interpolated NDC is not the closed form (fp32 plane equations, the
     fullscreen triangle bisected), and the RNG seed hashes its bits.  With the captured table (tests/golden/ref_ndc_*.npz:
     ulp deltas against the closed form) every pipeline reproduces the reference's bands of rows bit for bit."""
     from oracle.gen_fixtures import apply_ulp_delta, closed_form_ndc

@@ -119,9 +119,9 @@ def test_oracle_with_interpolated_ndc_table(scene):
     assert not np.array_equal(bits(o2["seed"][rows[0]:rows[1]]), bits(z["seed"]))
 
 
-@pytest.mark.parametrize("size", [(1280, 720), (3840, 2160)])
+@pytest.mark.parametrize("size", [(1280, 720), (3840, 2160), (7680, 4320)])
 def test_oracle_with_interpolated_ndc_at_the_benchmark_frame_sizes(scene, size):
-    """The same at 1280x720 and 3840x2160, where x AND y differ from the closed form on most pixels."""
+    """The same at 1280x720, 3840x2160 and 7680x4320, where x AND y differ from the closed form on most pixels."""
     w, h = size
     z = np.load(os.path.join(GOLDEN, f"ref_ndc_{w}x{h}.npz"))
     cx, cy = closed_form_ndc(w, h)
@@ -231,9 +231,9 @@ def test_depth_attachment_fixture_coverage():
     assert np.array_equal(oracle.depth_attachment(np.array([-1.0, 0.0, 0.5, 1.0, 2.0, np.nan], np.float32)), [0, 0, 8388608, 16777215, 16777215, 0])
 
 
-@pytest.mark.parametrize("name", ["bunny_720p_limit5", "bunny_4k_limit2"])
+@pytest.mark.parametrize("name", ["bunny_720p_limit5", "bunny_4k_limit2", "bunny_8k_limit5"])
 def test_oracle_matches_the_reference_whole_frame_digests(scene, name):
-    """The reference's WHOLE 1280x720 and 3840x2160 frames of the bunny scene, kept as SHA-256 digests of their planes
+    """The reference's WHOLE 1280x720, 3840x2160 and 7680x4320 frames of the bunny scene, kept as SHA-256 digests of their planes
     (ref_fullframe_digests.json): the restatement reproduces every one of them with the rasteriser's NDC table."""
     import hashlib
     import json
