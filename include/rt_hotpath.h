@@ -219,10 +219,14 @@ int rt_scene_set_sequence_batch(rt_scene *scene, int max_frames);
  * ray for which that cannot be decided locally is traversed again in the shader's own order.  That is the case when an earlier
  * reference of the triangle lies in a box the ray enters behind the hit point; when another triangle is hit at the same
  * distance or within 2^-18 of it; when a box is entered within 2^-18 of the closest distance known at that moment, so that
- * rounding could have turned the pruning decision the other way; and when the ray hits a triangle lying in a face plane of the
- * boxes around it.  What this does not cover by construction is a hit from a box that the ray enters MORE than that band
- * behind the hit point while the box containing the hit point does not list the triangle (a ray grazing a box face along
- * which the float triangle/box test of the build and the ray's slab test disagree): see the kernels' comment.  Every
+ * rounding could have turned the pruning decision the other way; when the ray hits a triangle lying in a face plane of the
+ * boxes around it; and when a primary ray lies in the plane of a triangle that also contains the camera position (the
+ * triangle test's determinant is rounding noise then and the shader may report the triangle at any distance, depending only on
+ * when it tests it: the triangles concerned are found per frame).  What this does not cover by construction is a hit from a
+ * box that the ray enters MORE than that band behind the hit point while the box containing the hit point does not list the
+ * triangle (a ray grazing a box face along which the float triangle/box test of the build and the ray's slab test disagree),
+ * and the same noise on a secondary ray whose origin and direction both lie in another triangle's plane: see the kernels'
+ * comment.  Every
  * bit-exactness test of this repository also runs in this mode.  Wavefront and persistent pipelines; the one-kernel pipeline
  * runs the reference's order in this mode (its waves' rays are coherent and most of them never enter the octree: near first
  * saves it 5 % of its node visits on the reference's scene, and on deep scenes the wave-wide pipelines are 2-3x faster anyway). */

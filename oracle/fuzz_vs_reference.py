@@ -1,4 +1,4 @@
-"""Test infrastructure, run by hand where /root/reference exists:  python -m oracle.fuzz_vs_reference [--views N] [--seed S] [--scene bunny|small]
+"""Test infrastructure, run by hand where /root/reference exists:  python -m oracle.fuzz_vs_reference [--views N] [--seed S] [--scene bunny|small|planes|deep|s100k|s1m]
 
 Random views (the generator of tests/fuzz_parity.py, frame sizes forced to powers of two so that the closed-form NDC
 equals the rasteriser's) rendered by the reference's own shader on llvmpipe (oracle/refrun.py) and by the CPU restatement
@@ -19,7 +19,9 @@ def main():
     ap.add_argument("--views", type=int, default=40)
     ap.add_argument("--seed", type=int, default=101)
     ap.add_argument("--any-size", action="store_true", help="frame sizes 1..200 in both directions; the rasteriser's interpolated NDC of each size is captured from llvmpipe and handed to the restatement as a table")
-    ap.add_argument("--scene", default="bunny", choices=["bunny", "small"], help="small: a cluster of meshes carrying all seven materials on triangles")
+    ap.add_argument("--scene", default="bunny", choices=["bunny", "small", "planes", "deep", "s100k", "s1m"],
+                    help="small: a cluster of meshes carrying all seven materials on triangles; planes: sheets with vertices, edges and corners on the octree's cell planes, "
+                         "half of the eyes on cell planes too; deep: a 26-level tree; s100k / s1m: the seeded 100 000-primitive / 1.28 M-triangle scenes")
     a = ap.parse_args()
     from fuzz_parity import random_view
     from oracle import oracle, refrun
@@ -31,12 +33,13 @@ def main():
         scene = bunny_scene()
     else:
         from raytracer_amd import scenes          # (host-side octree builder of the product; its arrays equal the octree oracle's)
-        scene = scenes.small_test_scene().as_dict()
+        scene = {"small": scenes.small_test_scene, "planes": scenes.plane_aligned_scene, "deep": scenes.deep_test_scene,
+                 "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m}[a.scene]().as_dict()
     sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
     osc = oracle.OracleScene(scene, sky)
     bad = 0
     for v in range(a.views):
-        u, _, _ = random_view(rng)
+        u, _, _ = random_view(rng, lattice=a.scene == "planes")
         w, h = [(128, 128), (128, 64), (64, 128)][int(rng.integers(0, 3))]
         # the aspect ratio baked into the matrix no longer matches the frame: any matrix is a valid input
         ndc = None

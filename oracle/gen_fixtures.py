@@ -217,6 +217,11 @@ SCENE_VIEWS = {
     "planes_axis_x": dict(scene="planes", cam=Camera(eye=(6.5, 4.0, 0.5), at=(0.0, 4.0, 0.5), fovy=0.9, aspect=255.0 / 129.0), size=(255, 129), kw=dict(max_recursion_limit=4, blur_amount=0.0)),
     "planes_down": dict(scene="planes", cam=Camera(eye=(0.5, 7.75, -0.5), at=(0.5, 0.0, -0.5), up=(0.0, 0.0, 1.0), fovy=1.1, aspect=1.0), size=(193, 193), kw=dict(max_recursion_limit=3, blur_amount=0.0)),
     "planes_inside": dict(scene="planes", cam=Camera(eye=(0.0, 5.0, 0.0), at=(1.0, 4.0, 1.0), fovy=1.3, aspect=1.0), size=(128, 128), kw=dict(max_recursion_limit=5, blur_amount=0.0)),
+    # a view the randomised runs found (tests/fuzz_parity.py --scene planes, seed 61, view 5820): eye and target are lattice points, and
+    # the primary ray of pixel (19, 84) lies IN the plane of a sheet triangle seven units away -- its Moeller-Trumbore determinant is
+    # rounding noise (2e-9), its numerator exactly zero, and the shader accepts it at distance 0 when it tests it before anything nearer
+    "planes_coplanar": dict(scene="planes", cam=Camera(eye=(6.5, 1.0, -5.5), at=(2.75, 2.75, -2.5), fovy=0.5, aspect=2.0), size=(256, 128),
+                            kw=dict(time=17.220732080302838, max_recursion_limit=6, blur_amount=0.0)),
 }
 
 

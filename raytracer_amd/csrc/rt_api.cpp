@@ -74,7 +74,7 @@ static const int kCandPipeline[RT_N_CAND] = {RT_PIPELINE_MEGAKERNEL, RT_PIPELINE
 struct rt_scene {
     int device = 0;
     RtDeviceScene d{};
-    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_dup = nullptr, *d_risky = nullptr, *d_sky = nullptr;
+    void *d_vertices = nullptr, *d_normals = nullptr, *d_refs = nullptr, *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_dup = nullptr, *d_risky = nullptr, *d_planes = nullptr, *d_sky = nullptr;
     unsigned long long *d_counters = nullptr;
     bool counting = false;
     // staging for host-memory targets
@@ -209,14 +209,14 @@ int ensure_workspace(rt_scene::Sub *s, size_t slots, size_t ranges) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t f4 = al(slots * 16), u1 = al(slots * 4);
     const size_t rg = al(ranges * 4);
-    const size_t total = 6 * f4 + 4 * u1 + 2 * rg + al(8 * 4) + al(96 * 16);
+    const size_t total = 6 * f4 + 4 * u1 + 2 * rg + al(8 * 4) + al((96 + RT_EYE_CAP) * 16);
     HIP_TRY(hipMalloc(&s->block, total));
     char *p = (char *)s->block;
     auto take = [&](size_t b) { char *q = p; p += b; return q; };
     for (int k = 0; k < 2; k++) { s->ws.pos_seed[k] = (float4 *)take(f4); s->ws.dir_pix[k] = (float4 *)take(f4); s->ws.color[k] = (float4 *)take(f4); }
     s->ws.t = (float *)take(u1); s->ws.sphere = (uint32_t *)take(u1); s->ws.tri = (uint32_t *)take(u1); s->ws.qt = (uint32_t *)take(u1);
     s->ws.live[0] = (uint32_t *)take(rg); s->ws.live[1] = (uint32_t *)take(rg);
-    s->ws.ctr = (uint32_t *)take(al(8 * 4)); s->ws.prim = (float4 *)take(al(96 * 16));
+    s->ws.ctr = (uint32_t *)take(al(8 * 4)); s->ws.prim = (float4 *)take(al((96 + RT_EYE_CAP) * 16));
     s->slots = slots;
     return RT_OK;
 }
@@ -359,6 +359,7 @@ int rt_scene_create_from(const float *vertices, const float *normals, size_t n_v
         if (e == hipSuccess) e = hipMalloc(&s->d_dup, n_ref * sizeof(uint32_t));
         if (e == hipSuccess) e = (hipError_t)rt_build_scene_records((const float *)s->d_vertices, (const float *)s->d_normals, (const uint32_t *)s->d_refs, (uint32_t)n_ref, (RtNodeRec *)s->d_nodes, nb.n_nodes,
                                                                     (RtTriRec *)s->d_tris, (RtShadeRec *)s->d_shade, (uint32_t *)s->d_dup, (RtTriRec **)&s->d_risky, &s->d.n_risky);
+        if (e == hipSuccess) e = (hipError_t)rt_build_plane_records((const RtTriRec *)s->d_tris, (uint32_t)n_ref, (RtPlaneRec **)&s->d_planes, &s->d.n_planes);
         if (e != hipSuccess) { rt_scene_destroy(s); return fail(e == hipErrorOutOfMemory ? RT_ENOMEM : RT_ENODEVICE, "triangle records: %s", hipGetErrorString(e)); }
     }
     if (hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_counters, 0, 128) != hipSuccess) {
@@ -368,7 +369,7 @@ int rt_scene_create_from(const float *vertices, const float *normals, size_t n_v
     // the uploaded arrays have served: every kernel reads the records derived from them (node, triangle and shading records)
     for (void **q : {&s->d_vertices, &s->d_normals, &s->d_refs}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     s->d.vertices = nullptr; s->d.normals = nullptr; s->d.tri_refs = nullptr;
-    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.shade = (const RtShadeRec *)s->d_shade; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.risky_tris = (const RtTriRec *)s->d_risky; s->d.sky = nullptr;
+    s->d.nodes = (const RtNodeRec *)s->d_nodes; s->d.tris = (const RtTriRec *)s->d_tris; s->d.shade = (const RtShadeRec *)s->d_shade; s->d.dup_parent = (const uint32_t *)s->d_dup; s->d.risky_tris = (const RtTriRec *)s->d_risky; s->d.planes = (const RtPlaneRec *)s->d_planes; s->d.sky = nullptr;
     s->d.n_vert = (uint32_t)n_vert; s->d.n_ref = (uint32_t)n_ref; s->d.n_nodes = nb.n_nodes;
     s->d.sky_w = s->d.sky_h = 0;
     for (int k = 0; k < 3; k++) { s->d.bounds_min[k] = bounds_min[k]; s->d.bounds_max[k] = bounds_max[k]; }
@@ -971,7 +972,7 @@ int rt_render_noalloc(rt_scene *s, const rt_frame *f, const rt_target *t) {
 int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     DeviceGuard guard(s->device);
-    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_shade, s->d_dup, s->d_risky, s->d_sky, s->d_counters};
+    void *p[] = {s->d_vertices, s->d_normals, s->d_refs, s->d_nodes, s->d_tris, s->d_shade, s->d_dup, s->d_risky, s->d_planes, s->d_sky, s->d_counters};
     for (void *q : p) if (q) (void)hipFree(q);
     free_staging(s);
     for (rt_scene::Sub &sb : s->sub) {

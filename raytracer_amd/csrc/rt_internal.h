@@ -61,6 +61,12 @@ struct alignas(16) RtShadeRec {
 };
 static_assert(sizeof(RtShadeRec) == 80, "shading record is five 16-byte quads");
 
+// One entry per distinct triangle for the per-frame search of triangles whose PLANE passes through the camera position (see
+// eye_planes_kernel in rt_kernels.hip): unit normal, first vertex, the slot of the triangle's first reference and |e1| + |e2|.
+struct alignas(16) RtPlaneRec { float n[3]; float v1x; float v1y, v1z; uint32_t slot; float edges; };
+static_assert(sizeof(RtPlaneRec) == 32, "plane record is two 16-byte quads");
+#define RT_EYE_CAP 32u       // eye-coplanar triangles a frame can list; more: every primary ray takes the reference's order
+
 struct RtDeviceScene {
     const float *vertices;     // [n_vert][4]  } the caller's arrays as uploaded: only alive while the records below are derived from them
     const float *normals;      // [n_vert][4]  } at scene creation, null afterwards
@@ -76,6 +82,8 @@ struct RtDeviceScene {
     // on its visiting order.  A ray that hits one of them is traversed in the reference's own order (see Exact in rt_kernels.hip).
     const RtTriRec *risky_tris; // [n_risky] copies of their records (one per triangle)
     uint32_t n_risky;           // RT_RISKY_TOO_MANY: more than RT_MAX_RISKY, the exact near-first order is not used for this scene
+    const RtPlaneRec *planes;   // [n_planes] one per distinct non-degenerate triangle
+    uint32_t n_planes;
     const uint8_t *sky;        // [6][sky_h][sky_w][4] or null
     uint32_t n_vert, n_ref, n_nodes;
     int32_t sky_w, sky_h;
@@ -101,6 +109,10 @@ struct RtLaunch {
     float *color, *depth, *hit_t;
     uint32_t *hit_kind, *hit_slot, *n_rays;
     unsigned long long *counters;   // 16 x u64 or null
+    // exact near-first order: the frame's eye-coplanar triangles (filled by rt_launch_render: a count and up to RT_EYE_CAP entries of
+    // unit normal + slot bits), or null
+    const uint32_t *eye_count;
+    const float4 *eye_list;
 };
 
 // Device workspace of the per-depth wavefront pipeline.  Path segments of one depth are addressed by slot; the
@@ -114,8 +126,8 @@ struct RtWorkspace {
     uint32_t *tri;         // closest triangle slot | 0x80000000 when a triangle is the closest hit so far
     uint32_t *qt;          // traversal queue: slots of the segments that enter the octree
     uint32_t *live[2];     // per slot range: number of live segments at this / the next depth
-    uint32_t *ctr;         // 8 queue counters
-    float4 *prim;          // per-frame (oc.xyz, c) of the 84 spheres for rays starting at the camera
+    uint32_t *ctr;         // 8 counters: the traversal queues' (QT_*) and, at [4], the number of eye-coplanar triangles of the frame
+    float4 *prim;          // per-frame (oc.xyz, c) of the 84 spheres for rays starting at the camera; from entry 96 on: the eye-coplanar triangles
 };
 
 // Several consecutive frames of a sequence traced by ONE launch of the one-lane-per-pixel kernel.  Samples of different
@@ -164,6 +176,8 @@ struct RtNodeBuild { RtNodeRec *nodes; uint32_t n_nodes, max_depth, error, error
 #define RT_MAX_RISKY 32u
 #define RT_RISKY_TOO_MANY 0xFFFFFFFFu
 #define RT_TOP_RECORDS 80u   // records of the three top levels (the root's block of 8, 8 + 64): the part of the tree every entering ray visits
+// The plane records of the scene's distinct triangles (hipMalloc'ed, the caller frees); returns a hipError_t value.
+int rt_build_plane_records(const RtTriRec *tris, uint32_t n_ref, RtPlaneRec **out, uint32_t *n_out);
 int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref, const float lo0[3], const float hi0[3], RtNodeBuild *out);
 // dup_parent: n_ref words (see RtDeviceScene).
 // risky / n_risky: see RtDeviceScene (*risky is hipMalloc'ed when *n_risky is in 1..RT_MAX_RISKY; the caller frees).

@@ -676,11 +676,19 @@ struct Walk {
 // use this mode at all.
 //
 // When step 1 finds no triangle closer than the initial distance, R -- which prunes at least as much -- finds none either.
-// What is NOT covered by construction: a triangle that is not face-coplanar, hit MORE than the band in front of every box that
-// lists it (the box containing the hit point does not list it and the ray runs on along the face it lies against for longer
-// than the band before it enters one that does), with another hit inside that stretch.  The llvmpipe records of a scene built for
-// this (sheet edges and corners exactly on cell planes, rays inside cell planes: tests/golden/refscene_planes_*.npz) and the
-// randomised comparisons with the CPU restatement run in this mode.
+//
+// The premise fails outright when a triangle test returns a distance that has nothing to do with where the triangle is: a ray that
+// lies IN the plane of a triangle has a Moeller-Trumbore determinant of rounding noise, and the test then accepts the triangle --
+// seven units away in the record that showed it -- at distance 0 or at any other.  R reports that if it happens to test the
+// triangle before a nearer hit prunes its cell; step 1 never makes the test.  For primary rays, which all start at the camera
+// position, the triangles this can happen with are found per frame and such rays take R's order (hits_eye_coplanar below).
+//
+// What is NOT covered by construction: a hit whose computed distance lies MORE than the band in front of every box that lists its
+// triangle, with another hit inside that stretch -- a triangle that is not face-coplanar whose cell does not list it where the hit
+// point is, the ray running on along that face for longer than the band; or a secondary ray whose origin AND direction lie in the
+// plane of another triangle to within rounding.  The llvmpipe records of a scene built for this (sheet edges and corners exactly on
+// cell planes, rays inside cell planes, eye and target on the lattice: tests/golden/refscene_planes_*.npz) and the randomised
+// comparisons with the CPU restatement run in this mode.
 struct Exact {
     uint32_t best_rank;       // rank of the node that holds closest_tri
     uint32_t best_id;         // the triangle behind closest_tri (RtTriRec::dup_first)
@@ -692,6 +700,43 @@ struct Exact {
     bool slot;                // the reference's SLOT is wanted (step 2), not only its distance and triangle
     DEVI void begin(float c0, bool want_slot) { best_rank = 0; best_id = 0; post_q = post_end = 0; closest0 = c0; closest_hi = c0; band = exact_band(c0); nf = true; tie = false; slot = want_slot; }
 };
+// Eye-coplanar triangles.  Every primary ray starts at the camera position.  When that point lies IN the plane of a triangle, a ray
+// whose direction lies in that plane too gives the Moeller-Trumbore test a determinant and a `u` numerator that are both rounding
+// noise (and a `t` numerator of exactly zero when the coordinates are exact): the test then accepts or rejects the triangle at
+// random, at a distance that has nothing to do with where the triangle is.  The reference reports such a hit if it happens to
+// test the triangle before a nearer hit prunes its cell, so the result depends on the visiting order alone and the near-first pass
+// cannot know about it (the cell is pruned, the test never made).  Seen with eye, target and triangle vertices on one lattice.
+// Per frame, eye_planes_kernel lists the triangles whose plane passes within 2^-18 of the camera position (relative to the
+// distances involved: sixteen times the rounding noise of the quantities that decide the test); a primary ray whose direction
+// lies within 2^-10 of the plane of a listed triangle AND whose own test of that triangle -- the reference's arithmetic on the
+// reference's operands -- accepts it takes the reference's order from the start, as after hits_risky.  More than RT_EYE_CAP
+// listed triangles: every primary ray of the frame does.
+__global__ __launch_bounds__(256) void eye_planes_kernel(const RtPlaneRec *__restrict__ planes, uint32_t n, float ex, float ey, float ez, uint32_t *__restrict__ count, float4 *__restrict__ list) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = reinterpret_cast<const float4 *>(planes)[2 * i], b = reinterpret_cast<const float4 *>(planes)[2 * i + 1];
+    const float tx = ex - a.w, ty = ey - b.x, tz = ez - b.y;
+    const float dist = a.x * tx + a.y * ty + a.z * tz;
+    const float scale = __builtin_fabsf(tx) + __builtin_fabsf(ty) + __builtin_fabsf(tz) + b.w;
+    if (!(__builtin_fabsf(dist) <= scale * 0x1p-18f)) return;
+    const uint32_t k = atomicAdd(count, 1u);
+    if (k < RT_EYE_CAP) list[k] = make_float4(a.x, a.y, a.z, b.z);     // (b.z: the slot's bits)
+}
+DEVI bool hits_eye_coplanar(const RtDeviceScene &S, const RtLaunch &L, const Ray &r) {
+    if (!L.eye_count) return false;
+    const uint32_t n = *L.eye_count;                   // (uniform: the common case is zero)
+    if (n == 0) return false;
+    if (n > RT_EYE_CAP) return true;
+    bool hit = false;
+    for (uint32_t k = 0; k < n; k++) {
+        const float4 e = L.eye_list[k];
+        if (__builtin_fabsf(r.dir.x * e.x + r.dir.y * e.y + r.dir.z * e.z) <= 0x1p-10f) {
+            const TriData d = load_triangle(S.tris + f2u(e.w));
+            hit = hit || ray_triangle(r, d) >= 0.0f;
+        }
+    }
+    return hit;
+}
 DEVI bool hits_risky(const RtDeviceScene &S, const TopLevels *top, const Ray &r) {
     bool hit = false;
     for (uint32_t k = 0; k < S.n_risky; k++) {
@@ -1530,6 +1575,21 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
     }
 }
 
+// Exact near-first order, frames with eye-coplanar triangles only (see hits_eye_coplanar): marks the queued first segments that
+// must take the reference's order by setting the sign bit of their closest distance, which the traversal kernel reads as that.
+__global__ __launch_bounds__(256) void mark_eye_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS) {
+    if (*L.eye_count == 0u) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= WS.ctr[QT_COUNT]) return;
+    const uint32_t slot = WS.qt[i];
+    const float4 a = WS.pos_seed[0][slot], b = WS.dir_pix[0][slot];
+    Ray ray;
+    ray.pos = F3(a.x, a.y, a.z);
+    ray.dir = F3(b.x, b.y, b.z);
+    ray.inv = rcp3(ray.dir);
+    if (hits_eye_coplanar(S, L, ray)) WS.t[slot] = -WS.t[slot];
+}
+
 template <int LEVELS, bool COUNT, int EXACT>
 __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t depth) {
     __shared__ uint32_t lds_stack[LEVELS * 256];
@@ -1581,12 +1641,15 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
                 ray.pos = F3(a.x, a.y, a.z);
                 ray.dir = F3(b.x, b.y, b.z);
                 ray.inv = rcp3(ray.dir);
-                closest = WS.t[slot];
+                // (the sign bit: spheres_kernel's mark on a primary ray that must take the reference's order, see hits_eye_coplanar)
+                const float ct = WS.t[slot];
+                const bool marked = EXACT != 0 && (f2u(ct) >> 31) != 0u;
+                closest = __builtin_fabsf(ct);
                 closest_tri = 0; tri_hit = false;
                 walk.begin(st, order_key(ray, L.near_first != 0u));
                 if (EXACT) {
                     x.begin(closest, want_slot);
-                    if (hits_risky(S, &lds_top, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
+                    if (hits_risky(S, &lds_top, ray) || marked) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
                 }
                 has = true;
                 if (COUNT) cn.entered++;
@@ -1863,7 +1926,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
                     walk.begin(st, order_key(ray, L.near_first != 0u));
                     if (EXACT) {
                         x.begin(closest, seg == 0u && L.hit_slot != nullptr);
-                        if (hits_risky(S, &lds_top, ray)) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
+                        if (hits_risky(S, &lds_top, ray) || (seg == 0u && hits_eye_coplanar(S, L, ray))) { x.nf = false; walk.begin(st, 0u); if (COUNT) cn.fallbacks++; }
                     }
                     traversing = true;
                 }
@@ -1930,11 +1993,14 @@ void launch_traverse(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
 
 }  // namespace
 
+// The persistent kernel's block: the tile counters, (development builds: wave time stamps,) then the frame's eye-coplanar
+// triangles -- a count in the first of four words, RT_EYE_CAP entries.  Zeroed by every launch.
 #ifdef PATH_TRACE
-size_t rt_pool_bytes() { return (size_t)PATH_POOLS * PATH_POOL_STRIDE * sizeof(uint32_t) + 16384 * 16; }
+#define PATH_EYE_WORDS ((size_t)PATH_POOLS * PATH_POOL_STRIDE + 16384 * 4)
 #else
-size_t rt_pool_bytes() { return (size_t)PATH_POOLS * PATH_POOL_STRIDE * sizeof(uint32_t); }
+#define PATH_EYE_WORDS ((size_t)PATH_POOLS * PATH_POOL_STRIDE)
 #endif
+size_t rt_pool_bytes() { return (PATH_EYE_WORDS + 4 + RT_EYE_CAP * 4) * sizeof(uint32_t); }
 // Exhaustive comparison of rcp_ieee / sqrt_ieee with the compiler's correctly rounded sequences: op 0: 1/x, op 1: sqrt(x),
 // over all 2^32 bit patterns.  out[0] = number of inputs whose results differ in any bit (NaN results compare equal to
 // NaN results), out[1] = the first such input found.
@@ -1970,7 +2036,9 @@ size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows) {
 }
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows) { return rt_workspace_ranges(width, n_local_rows) * RANGE; }
 
-int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe, const RtBatch *batch) {
+int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L_in, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe, const RtBatch *batch) {
+    RtLaunch L = L_in;
+    L.eye_count = nullptr; L.eye_list = nullptr;
     const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
     if (tiles_x == 0 || tiles_y == 0) return 0;
     const uint32_t n_tiles = tiles_x * tiles_y;
@@ -1985,6 +2053,11 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         const uint32_t n_units = n_tiles * 4u;
         const uint32_t wgs = min(n_cu * PATH_WG_PER_CU, (n_units + 3u) / 4u);
         (void)hipMemsetAsync(pool, 0, rt_pool_bytes(), st);
+        if (L.near_first == 2u && S.n_planes) {
+            L.eye_count = pool + PATH_EYE_WORDS; L.eye_list = reinterpret_cast<const float4 *>(pool + PATH_EYE_WORDS + 4);
+            hipLaunchKernelGGL(eye_planes_kernel, dim3((S.n_planes + 255u) / 256u), dim3(256), 0, st, S.planes, S.n_planes, L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2],
+                               pool + PATH_EYE_WORDS, reinterpret_cast<float4 *>(pool + PATH_EYE_WORDS + 4));
+        }
         mark(0);
         if (need <= 12) launch_path<12>(S, L, pool, n_tiles, st, dim3(wgs));
         else if (need <= 20) launch_path<20>(S, L, pool, n_tiles, st, dim3(wgs));
@@ -2009,11 +2082,17 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L, const RtWorkspac
         const dim3 tgrid((L.n_cu ? L.n_cu : 256u) * TRAVERSE_WG_PER_CU);             // persistent traversal workgroups
         (void)hipMemsetAsync(WS->ctr, 0, 8 * sizeof(uint32_t), st);
         hipLaunchKernelGGL(primary_sphere_kernel, dim3(1), dim3(128), 0, st, L, WS->prim);
+        if (L.near_first == 2u && S.n_planes) {
+            L.eye_count = WS->ctr + 4; L.eye_list = WS->prim + 96;
+            hipLaunchKernelGGL(eye_planes_kernel, dim3((S.n_planes + 255u) / 256u), dim3(256), 0, st, S.planes, S.n_planes, L.u.camera_position[0], L.u.camera_position[1], L.u.camera_position[2],
+                               WS->ctr + 4, WS->prim + 96);
+        }
         // (every depth is enqueued: a depth no path reaches costs three launches that find empty ranges and an empty queue,
         // whereas asking the device whether any path is left would block the caller inside an enqueue)
         const uint32_t limit = L.u.max_recursion_limit;
         for (uint32_t d = 0; d < limit; d++) {
             if (d == 0) hipLaunchKernelGGL(spheres_kernel, grid, dim3(256), 0, st, S, L, *WS, n_tiles);    // (later depths: inside the previous shade_kernel)
+            if (d == 0 && L.eye_count && S.n_nodes) hipLaunchKernelGGL(mark_eye_kernel, dim3(grid.x * (RANGE / 256u)), dim3(256), 0, st, S, L, *WS);
             if (S.n_nodes) {
                 const bool t = timed && probe->used < probe->capacity;
                 if (t) mark(0);

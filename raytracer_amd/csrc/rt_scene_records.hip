@@ -214,6 +214,25 @@ __global__ __launch_bounds__(BLOCK) void leaf_triangle_kernel(RtNodeRec *__restr
     nodes[i].first_id = r.dup_first;
 }
 
+// One plane record per distinct triangle (the first reference of its run) with a non-zero normal; `out` null: only counts.
+__global__ __launch_bounds__(BLOCK) void plane_records_kernel(const RtTriRec *__restrict__ tris, uint32_t n_ref, uint32_t *__restrict__ count, RtPlaneRec *__restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_ref) return;
+    const RtTriRec r = tris[i];
+    if (r.dup_pos != r.dup_first) return;
+    const float nx = r.e1y * r.e2z - r.e1z * r.e2y, ny = r.e1z * r.e2x - r.e1x * r.e2z, nz = r.e1x * r.e2y - r.e1y * r.e2x;
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    if (!(len > 0.0f) || !(len < __builtin_inff())) return;
+    const uint32_t k = atomicAdd(count, 1u);
+    if (!out) return;
+    RtPlaneRec p;
+    p.n[0] = nx / len; p.n[1] = ny / len; p.n[2] = nz / len;
+    p.v1x = r.v1[0]; p.v1y = r.v1[1]; p.v1z = r.v1[2];
+    p.slot = i;
+    p.edges = sqrtf(r.e1x * r.e1x + r.e1y * r.e1y + r.e1z * r.e1z) + sqrtf(r.e2x * r.e2x + r.e2y * r.e2y + r.e2z * r.e2z);
+    out[k] = p;
+}
+
 inline uint32_t grid_for(size_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
 
 struct Buf {
@@ -389,4 +408,22 @@ int rt_build_scene_records(const float *vertices, const float *normals, const ui
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     return (int)e;
+}
+
+int rt_build_plane_records(const RtTriRec *tris, uint32_t n_ref, RtPlaneRec **out, uint32_t *n_out) {
+    *out = nullptr; *n_out = 0;
+    if (n_ref == 0) return 0;
+    Buf count;
+    hipError_t e;
+    uint32_t n = 0;
+    if ((e = count.alloc(4)) != hipSuccess || (e = hipMemset(count.p, 0, 4)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(plane_records_kernel, dim3(grid_for(n_ref)), dim3(BLOCK), 0, nullptr, tris, n_ref, (uint32_t *)count.p, (RtPlaneRec *)nullptr);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(&n, count.p, 4, hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+    if (n == 0) return 0;
+    if ((e = hipMalloc((void **)out, (size_t)n * sizeof(RtPlaneRec))) != hipSuccess) return (int)e;
+    if ((e = hipMemset(count.p, 0, 4)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(plane_records_kernel, dim3(grid_for(n_ref)), dim3(BLOCK), 0, nullptr, tris, n_ref, (uint32_t *)count.p, *out);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) { (void)hipFree(*out); *out = nullptr; return (int)e; }
+    *n_out = n;
+    return 0;
 }

@@ -21,6 +21,20 @@ def random_view(rng, lattice=False):
         # lattice point, no lens blur -- rays that run inside cell planes and through sheet edges and corners
         eye = np.round(rng.uniform((-7, 0.25, -7), (7, 7.75, 7)) * 4) / 4
         axis = rng.integers(0, 3)
+        if rng.uniform() < 0.4:
+            # grazing bundles: the eye on (or a hair beside) cell planes, the view direction an axis tilted by 2^-8 .. 2^-22 and a field
+            # of view of 2^-6 .. 2^-16 radians, so that EVERY primary ray of the frame crosses cell planes at grazing incidence, close
+            # to the sheet edges and corners that lie in them
+            eye = eye + rng.choice([0.0, 1.0, -1.0], 3) * 2.0 ** -float(rng.integers(10, 23))
+            at = eye.copy(); at[axis] += 1.0 if eye[axis] < 0 or axis == 1 and eye[axis] < 4 else -1.0
+            for k in range(3):
+                if k != axis and rng.uniform() < 0.8:
+                    at[k] += float(rng.choice([1.0, -1.0])) * 2.0 ** -float(rng.integers(8, 23))
+            up = (0.0, 0.0, 1.0) if axis == 1 else (0.0, 1.0, 0.0)
+            w, h = [(128, 128), (192, 64), (64, 160), (256, 128)][rng.integers(0, 4)]
+            cam = Camera(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), up=up, fovy=2.0 ** -float(rng.integers(6, 17)), aspect=w / h)
+            u = Uniforms.from_camera(cam, time=float(rng.choice([0.0, rng.uniform(0, 100)])), max_recursion_limit=int(rng.integers(1, 5)), blur_amount=0.0)
+            return u.pack(), w, h
         if rng.uniform() < 0.6:
             at = eye.copy(); at[axis] += 1.0 if eye[axis] < 0 or axis == 1 and eye[axis] < 4 else -1.0
         else:

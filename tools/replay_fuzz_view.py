@@ -12,10 +12,10 @@ from raytracer_amd import api, scenes
 
 scene, seed, view = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rng = np.random.default_rng(seed)
-oc = {"bunny": scenes.default_octree, "small": scenes.small_test_scene, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "deep": scenes.deep_test_scene}[scene]()
+oc = {"bunny": scenes.default_octree, "small": scenes.small_test_scene, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "deep": scenes.deep_test_scene, "planes": scenes.plane_aligned_scene}[scene]()
 sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
 for v in range(view + 1):
-    u, w, h = fuzz_parity.random_view(rng)
+    u, w, h = fuzz_parity.random_view(rng, lattice=scene == "planes")
 np.save(os.path.join(ROOT, "gpurun_out", f"replay_{scene}_{seed}_{view}_uniforms.npy"), u)
 print("view", view, w, h, "limit", int(u[19:20].view(np.uint32)[0]))
 sc = api.Scene.from_octree(oc); sc.set_skybox(sky)
