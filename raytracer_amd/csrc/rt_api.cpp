@@ -100,7 +100,7 @@ struct rt_scene {
         uint32_t *pool = nullptr;   // tile counter of the persistent path kernel
         // one-lane-per-pixel kernel: per-unit cost measured by the last launch and the start order derived from it
         uint32_t *lpt_cost = nullptr, *lpt_order = nullptr;
-        size_t lpt_units = 0;
+        size_t lpt_units = 0, lpt_cap = 0;   // units of the geometry the block is used for, and units it has room for
         uint64_t lpt_key = 0;       // frame geometry the order belongs to (0: none)
         uint32_t lpt_age = 0;       // launches since the order was last rebuilt
     } sub[RT_MAX_SUBFRAMES];
@@ -108,6 +108,9 @@ struct rt_scene {
     hipEvent_t fork_ev = nullptr;
     void *stage = nullptr;      // sample staging of batched sequence launches (RtBatch)
     size_t stage_elems = 0;
+    // blocks that were outgrown while work that reads them may still be in flight: released with the scene (releasing them
+    // inside an enqueue would block the caller until the device is idle)
+    std::vector<void *> retired;
     int max_batch = 0;          // 0: automatic; 1: never batch
     int order = RT_ORDER_AUTO;
     int last_pipeline = -1, last_order = -1;   // what the last render call ran with (rt_scene_last_mode)
@@ -203,9 +206,11 @@ void hot_tiles(const uint32_t rect[4], bool any, uint32_t band_rows, uint32_t pa
 }
 
 // One allocation carved into the workspace planes (256-byte aligned pieces).
-int ensure_workspace(rt_scene::Sub *s, size_t slots, size_t ranges) {
+int ensure_workspace(rt_scene *sc, rt_scene::Sub *s, size_t slots, size_t ranges) {
     if (s->slots >= slots && s->block) return RT_OK;
-    if (s->block) { (void)hipFree(s->block); s->block = nullptr; s->slots = 0; }
+    // (an outgrown block is retired, not released: work of earlier calls may still read it.  Growing by at least half keeps the sum
+    // of the retired blocks below twice the final one.)
+    if (s->block) { sc->retired.push_back(s->block); s->block = nullptr; slots = std::max(slots, s->slots + s->slots / 2); ranges = std::max(ranges, (slots + 1023) / 1024); s->slots = 0; }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t f4 = al(slots * 16), u1 = al(slots * 4);
     const size_t rg = al(ranges * 4);
@@ -697,7 +702,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             fj.band_parts = f->band_parts * K; fj.band_part = j * f->band_parts + f->band_part;
             const uint32_t rows = band_rows_of(&fj);
             if (wavefront) {
-                int wrc = ensure_workspace(&s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
+                int wrc = ensure_workspace(s, &s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
                 if (wrc != RT_OK) {
                     // (about 112 bytes per pixel.)  Under automatic selection a pipeline that cannot get its workspace is
                     // given up for this workload instead of failing the render: the one-kernel pipeline needs none.
@@ -731,9 +736,13 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         const size_t units = rt_render_units(Li.width, Li.n_local_rows);
         if (units == 0) return 0;
         if (sb.lpt_units != units) {
-            if (sb.lpt_cost) { if (hipDeviceSynchronize() != hipSuccess) return 1; (void)hipFree(sb.lpt_cost); sb.lpt_cost = nullptr; }
-            if (hipMalloc((void **)&sb.lpt_cost, 2 * units * sizeof(uint32_t)) != hipSuccess) { sb.lpt_units = 0; return 1; }
-            sb.lpt_order = sb.lpt_cost + units;
+            if (sb.lpt_cap < units) {
+                if (sb.lpt_cost) s->retired.push_back(sb.lpt_cost);
+                sb.lpt_cost = nullptr; sb.lpt_cap = 0; sb.lpt_units = 0;
+                if (hipMalloc((void **)&sb.lpt_cost, 2 * units * sizeof(uint32_t)) != hipSuccess) return 1;
+                sb.lpt_cap = units;
+            }
+            sb.lpt_order = sb.lpt_cost + sb.lpt_cap;
             sb.lpt_units = units;
             sb.lpt_key = 0;
             if (hipMemsetAsync(sb.lpt_cost, 0, units * sizeof(uint32_t), stream) != hipSuccess) return 1;
@@ -788,7 +797,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
                     continue;
                 }
                 if (rt_batch_groups((uint32_t)nb) > 1u && s->stage_elems < nb * px) {
-                    if (s->stage) { if (hipDeviceSynchronize() != hipSuccess) return 1; (void)hipFree(s->stage); s->stage = nullptr; s->stage_elems = 0; }
+                    if (s->stage) { s->retired.push_back(s->stage); s->stage = nullptr; s->stage_elems = 0; }
                     if (hipMalloc(&s->stage, batch * px * 16) != hipSuccess) return 1;
                     s->stage_elems = batch * px;
                 }
@@ -986,6 +995,7 @@ int rt_scene_destroy(rt_scene *s) {
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
     if (s->last_use) (void)hipEventDestroy(s->last_use);
     if (s->stage) (void)hipFree(s->stage);
+    for (void *q : s->retired) (void)hipFree(q);
     if (s->tuner.a) (void)hipEventDestroy(s->tuner.a);
     if (s->tuner.b) (void)hipEventDestroy(s->tuner.b);
     delete s;
