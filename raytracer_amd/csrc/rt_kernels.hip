@@ -1641,7 +1641,8 @@ __global__ __launch_bounds__(256) void traverse_kernel(RtDeviceScene S, RtLaunch
                 ray.pos = F3(a.x, a.y, a.z);
                 ray.dir = F3(b.x, b.y, b.z);
                 ray.inv = rcp3(ray.dir);
-                // (the sign bit: spheres_kernel's mark on a primary ray that must take the reference's order, see hits_eye_coplanar)
+                // (the sign bit: mark_eye_kernel's mark on a first segment that must take the reference's order, see hits_eye_coplanar;
+                // the distance a segment is queued with is the sphere loop's, strictly positive or infinite: sphere_accept)
                 const float ct = WS.t[slot];
                 const bool marked = EXACT != 0 && (f2u(ct) >> 31) != 0u;
                 closest = __builtin_fabsf(ct);
