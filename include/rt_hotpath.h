@@ -125,8 +125,9 @@ int rt_set_device(int device);     /* device used by subsequent rt_scene_create 
  * words (m_compressed_node_buffer, Octree.hpp:35; format written at Octree.cpp:44-75).  n_ref and n_words may be 0
  * (no mesh).  The node buffer is validated and re-flattened into 64-byte node records for the device; per triangle
  * reference a 48-byte intersection record and an 80-byte shading record (vertices, edges, normals, material) are derived,
- * and the uploaded copies of the four arrays are released: a scene holds about 132 bytes per reference plus 64 per node
- * record (eight records per node with children) in device memory. */
+ * and the uploaded copies of the four arrays are released: a scene holds about 132 bytes per reference, 32 per distinct
+ * triangle (its plane: see RT_ORDER_NEAR_FIRST_EXACT) and 64 per node record (eight records per node with children) in
+ * device memory. */
 int rt_scene_create(const float *vertices, const float *normals, size_t n_vert,
                     const uint32_t *tri_refs, size_t n_ref,
                     const uint32_t *nodes, size_t n_words,
