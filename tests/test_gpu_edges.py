@@ -261,3 +261,38 @@ def test_renders_of_one_scene_on_two_streams_are_ordered(bunny_octree, test_sky)
         for k in range(len(us)):
             assert np.array_equal(bits(cols[k].cpu().numpy()), bits(want[k])), (pipe, k)
     sc.close()
+
+
+def test_growing_frames_enqueued_back_to_back(bunny_octree, test_sky):
+    """Frames of growing size enqueued with sync = 0 on one stream, in every pipeline and as batched sequences: each call outgrows
+    the scene's workspace, cost map or sample staging while the previous call's kernels may still be running on them (the outgrown
+    blocks are kept until the scene is destroyed).  Every target must hold its own complete frame."""
+    import torch
+    from oracle import oracle
+    sizes = [(160, 96), (416, 240), (800, 448), (1280, 720)]
+    osc = oracle.OracleScene(bunny_octree.as_dict(), test_sky)
+    us = {s: Uniforms.from_camera(Camera(aspect=s[0] / s[1]), max_recursion_limit=3).pack() for s in sizes}
+    want = {s: osc.render(us[s], s[0], s[1], taps=False)["rgba"] for s in sizes}
+    stream = torch.cuda.current_stream().cuda_stream
+    for pipe in PIPELINES:
+        sc = api.Scene.from_octree(bunny_octree, device=0)
+        sc.set_skybox(test_sky)
+        sc.set_pipeline(pipe)
+        cols, seqs = {}, {}
+        torch.cuda.synchronize()
+        for s in sizes:
+            w, h = s
+            cols[s] = torch.zeros((h, w, 4), device="cuda")
+            seqs[s] = torch.zeros((h, w, 4), device="cuda")
+            tg = api.rt_target()
+            tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 0, cols[s].data_ptr()
+            sc.render_raw(api.make_frame(us[s], w, h, blend=False, stream=stream), tg)
+            tg2 = api.rt_target()
+            tg2.memory, tg2.sync, tg2.color = api.RT_MEM_DEVICE, 0, seqs[s].data_ptr()
+            # (twelve identical frames, the first without blending: the accumulated frame equals the single one)
+            sc.render_sequence_raw([api.make_frame(us[s], w, h, accum_index=1, blend=False, stream=stream) for _ in range(12)], tg2)
+        torch.cuda.synchronize()
+        for s in sizes:
+            assert np.array_equal(bits(cols[s].cpu().numpy()), bits(want[s])), (pipe, s)
+            assert np.array_equal(bits(seqs[s].cpu().numpy()), bits(want[s])), (pipe, s, "sequence")
+        sc.close()
