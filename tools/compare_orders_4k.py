@@ -2,7 +2,7 @@
 """Development aid (GPU box): many 4K frames of a scene rendered in the shader's child order and in the exact near-first order (wavefront
 pipeline, device targets), compared on the device: pixels whose colour or depth bits differ, per frame and in total.  The frames differ
 in time (sub-pixel jitter, scattering) and camera pose, so the count is over billions of distinct rays.
-usage: tools/compare_orders_4k.py <bunny|s100k|s1m> [frames] [limit]"""
+usage: tools/compare_orders_4k.py <bunny|s100k|s1m> [frames] [limit] [wavefront|persistent]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,11 +15,12 @@ from raytracer_amd.params import Uniforms
 name = sys.argv[1]
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 limit = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+pipeline = sys.argv[4] if len(sys.argv) > 4 else "wavefront"
 W, H = 3840, 2160
 oc = {"bunny": scenes.default_octree, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m}[name](device=0)
 sc = api.Scene.from_dict(oc.as_dict(), device=0)
 sc.set_skybox(scenes.procedural_skybox(900))
-sc.set_pipeline("wavefront")
+sc.set_pipeline(pipeline)
 stream = torch.cuda.current_stream().cuda_stream
 bufs = {o: (torch.zeros((H, W, 4), device="cuda"), torch.zeros((H, W), device="cuda")) for o in ("reference", "near_first_exact")}
 rng = np.random.default_rng(7)
@@ -34,7 +35,7 @@ for k in range(frames):
         tg = api.rt_target()
         tg.memory, tg.sync, tg.color, tg.depth = api.RT_MEM_DEVICE, 1, col.data_ptr(), dep.data_ptr()
         sc.render_raw(api.make_frame(u, W, H, accum_index=1, blend=False, stream=stream), tg)
-        assert sc.last_mode() == ("wavefront", order), sc.last_mode()
+        assert sc.last_mode() == (pipeline, order), sc.last_mode()
     (ca, da), (cb, db) = bufs["reference"], bufs["near_first_exact"]
     bad = (ca.view(torch.int32) != cb.view(torch.int32)).any(-1) | (da.view(torch.int32) != db.view(torch.int32))
     n = int(bad.sum())
@@ -44,5 +45,5 @@ for k in range(frames):
         print(f"frame {k}: {n} differing pixel(s), first at (y, x) = ({int(ys[0])}, {int(xs[0])}); depth {float(da[ys[0], xs[0]])!r} vs {float(db[ys[0], xs[0]])!r}", flush=True)
     if k % 20 == 19:
         print(f"{k + 1} frames, {total} differing pixels so far", flush=True)
-print(f"done: {name}, limit {limit}: {frames} frames of {W}x{H}, {total} differing pixels")
+print(f"done: {name}, {pipeline}, limit {limit}: {frames} frames of {W}x{H}, {total} differing pixels")
 sc.close()
