@@ -114,7 +114,7 @@ DEVI float log2_poly(float v) {
 DEVI float exp2_poly(float v) {
     v = fminf(fmaxf(v, -126.99999f), 129.0f);
     const float ip = __builtin_floorf(v), fp = v - ip;
-    const float scale = u2f((uint32_t)(((int)ip + 127) << 23));
+    const float scale = u2f((uint32_t)((int)ip + 127) << 23);   // (in unsigned arithmetic: 256 << 23 for an argument of 129 wraps to the sign bit, as pslld does)
     const float f2 = fp * fp;
     const float even = fmaf(f2, fmaf(f2, (float)0.008989340090494664, (float)0.24015361704437538), 1.0f);
     const float odd = fmaf(f2, fmaf(f2, (float)0.001877576675191479, (float)0.055826318053295666), (float)0.693153073200169);
