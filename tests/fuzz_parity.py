@@ -74,6 +74,36 @@ def random_view(rng, lattice=False):
     return u.pack(), w, h
 
 
+def in_plane_view(rng, vertices, tri_refs):
+    """A view whose eye lies in the plane of a randomly chosen scene triangle (as exactly as binary32 coordinates allow: the eye is the
+    triangle's first vertex plus multiples of its edges) and looks at another point of that plane, with no lens blur: a column or row of
+    primary rays then lies in the triangle's plane, where its Moeller-Trumbore determinant is rounding noise."""
+    from raytracer_amd.camera import Camera
+    from raytracer_amd.params import Uniforms
+    t = tri_refs[int(rng.integers(0, len(tri_refs)))]
+    v0, v1, v2 = (np.asarray(vertices[int(i)][:3], np.float64) for i in t[:3])
+    e1, e2 = v1 - v0, v2 - v0
+    n = np.cross(e1, e2)
+    if not np.linalg.norm(n) > 0:
+        return None
+    scale = float(rng.uniform(1.0, 6.0)) / max(np.linalg.norm(e1), np.linalg.norm(e2), 1e-6)
+    a, b = rng.uniform(-1, 1, 2) * scale
+    if rng.uniform() < 0.3:          # small integer multiples of the edges: the eye's coordinates stay (nearly) exact
+        a, b = np.round(rng.uniform(-8, 8, 2))
+    eye = np.float32(v0 + a * e1 + b * e2)
+    at = np.float32(v0 + rng.uniform(0, 1) * e1 + rng.uniform(0, 1) * e2) if rng.uniform() < 0.7 else np.float32(v0 + rng.uniform(-3, 3) * e1 * scale + rng.uniform(-3, 3) * e2 * scale)
+    if not np.linalg.norm(at.astype(np.float64) - eye) > 1e-3:
+        return None
+    up = n / np.linalg.norm(n) if rng.uniform() < 0.5 else np.cross(n, at.astype(np.float64) - eye)   # the plane shows as a column or as a row of pixels
+    if not np.linalg.norm(up) > 0:
+        return None
+    w, h = [(129, 65), (65, 129), (128, 128), (193, 64)][int(rng.integers(0, 4))]          # odd sizes: a centre column / row with ndc 0
+    cam = Camera(eye=tuple(float(x) for x in eye), at=tuple(float(x) for x in at), up=tuple(float(x) for x in up / np.linalg.norm(up)),
+                 fovy=float(rng.choice([0.05, 0.3, 0.9, 1.6])), aspect=w / h)
+    u = Uniforms.from_camera(cam, time=float(rng.uniform(0, 50)), max_recursion_limit=int(rng.integers(1, 5)), blur_amount=0.0)
+    return u.pack(), w, h
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=200)
@@ -86,6 +116,7 @@ def main():
     ap.add_argument("--order", default="reference", choices=["reference", "near_first_exact"],
                     help="child order of the traversal for the bit-exact comparison: the shader's own, or nearest first with the shader's result "
                          "(every view is then also rendered without the debug planes, where that mode skips resolving the slot)")
+    ap.add_argument("--eye-in-plane", action="store_true", help="two thirds of the views with the eye IN the plane of a random scene triangle, looking along that plane, no lens blur")
     a = ap.parse_args()
     from oracle import oracle
     from raytracer_amd import api, scenes
@@ -93,6 +124,7 @@ def main():
     oc = {"bunny": scenes.default_octree, "small": scenes.small_test_scene, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m, "deep": scenes.deep_test_scene, "planes": scenes.plane_aligned_scene}[a.scene]()
     sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
     osc = oracle.OracleScene(oc.as_dict(), sky)
+    verts, refs = np.asarray(oc.m_vertecies).reshape(-1, 4), np.asarray(oc.m_compressed_triangles).reshape(-1, 4)
     sc = api.Scene.from_octree(oc); sc.set_skybox(sky)
     sc.set_traversal_order(a.order)
     fallbacks = checks = 0
@@ -100,6 +132,10 @@ def main():
     nf_pixels = nf_diff = nf_beyond = nf_slot = 0
     for v in range(a.views):
         u, w, h = random_view(rng, lattice=a.scene == "planes")
+        if a.eye_in_plane and rng.uniform() < 0.67:
+            pv = in_plane_view(rng, verts, refs)
+            if pv is not None:
+                u, w, h = pv
         ndc = None
         if a.ndc_table:
             x = (np.float32(2.0) * (np.arange(w, dtype=np.float32) + np.float32(0.5)) / np.float32(w) - np.float32(1.0)).astype(np.float32)
