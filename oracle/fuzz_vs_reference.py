@@ -22,8 +22,9 @@ def main():
     ap.add_argument("--scene", default="bunny", choices=["bunny", "small", "planes", "deep", "s100k", "s1m"],
                     help="small: a cluster of meshes carrying all seven materials on triangles; planes: sheets with vertices, edges and corners on the octree's cell planes, "
                          "half of the eyes on cell planes too; deep: a 26-level tree; s100k / s1m: the seeded 100 000-primitive / 1.28 M-triangle scenes")
+    ap.add_argument("--eye-in-plane", action="store_true", help="two thirds of the views with the eye IN the plane of a random scene triangle, looking along that plane (tests/fuzz_parity.py in_plane_view)")
     a = ap.parse_args()
-    from fuzz_parity import random_view
+    from fuzz_parity import random_view, in_plane_view
     from oracle import oracle, refrun
     from oracle.gen_fixtures import bunny_scene
     refrun.build()
@@ -38,12 +39,22 @@ def main():
     sky = rng.integers(0, 256, size=(6, 48, 48, 4), dtype=np.uint8)
     osc = oracle.OracleScene(scene, sky)
     bad = 0
+    ndc_cache = {}
     for v in range(a.views):
         u, _, _ = random_view(rng, lattice=a.scene == "planes")
         w, h = [(128, 128), (128, 64), (64, 128)][int(rng.integers(0, 3))]
+        in_plane_ndc = None
+        if a.eye_in_plane and rng.uniform() < 0.67:
+            pv = in_plane_view(rng, np.asarray(scene["vertices"]).reshape(-1, 4), np.asarray(scene["tri_refs"]).reshape(-1, 4))
+            if pv is not None:      # (its own, mostly odd, frame size: the rasteriser's NDC of that size is captured like with --any-size)
+                from oracle.gen_fixtures import capture_ndc
+                u, w, h = pv
+                if (w, h) not in ndc_cache:
+                    ndc_cache[(w, h)] = capture_ndc(w, h)
+                in_plane_ndc = ndc_cache[(w, h)]
         # the aspect ratio baked into the matrix no longer matches the frame: any matrix is a valid input
-        ndc = None
-        if a.any_size:
+        ndc = in_plane_ndc
+        if a.any_size and in_plane_ndc is None:
             from oracle.gen_fixtures import capture_ndc
             w, h = int(rng.integers(1, 201)), int(rng.integers(1, 201))
             ndc = capture_ndc(w, h)
