@@ -278,8 +278,7 @@ __constant__ SphereGrid c_sphere_grid = make_sphere_grid();
 // intersection
 // ------------------------------------------------------------------------------------------------
 struct Ray { f3 pos, dir, inv; };
-struct Hit { bool has_hit; f3 position, normal; uint32_t material_id, portal_id; };
-struct PrimaryTap { uint32_t kind, slot; float t; };
+struct Hit { bool has_hit; f3 position, normal; uint32_t material_id, portal_id; uint32_t kind, slot; float t; };   // kind / slot / t: what the debug planes of a first segment show (RT_HIT_*, sphere index or triangle slot, distance)
 struct Counters { uint32_t rays, pops, tri_tests, box_tests, tri_shaded, entered, sph_tests, lds_pops, fallbacks, cand_checks; };
 
 // frag:417-425
@@ -947,7 +946,7 @@ DEVI f3 barycentric(f3 p, f3 a, f3 v0, f3 v1) {
 // Everything of FindIntersection after the octree loop (frag:517-562): cylinder, portals, hit assembly.
 template <bool COUNT>
 DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const PortalBasis *portals, const Ray &r, float closest, uint32_t closest_i, uint32_t closest_tri,
-                             bool tri_hit, PrimaryTap *tap, Counters &cn) {
+                             bool tri_hit, Counters &cn) {
     bool cyl_hit = false;
     f3 cyl_n = F3(0.0f, 0.0f, 0.0f);
     const float cyl_t = ray_cylinder(r, closest, cyl_n);
@@ -962,26 +961,25 @@ DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const
     const float p2 = ray_portal(r, pp2, pd2, portals[first + 1u], U.portal_width, U.portal_height, closest);
 
     Hit h;
-    h.has_hit = false; h.position = F3(0, 0, 0); h.normal = F3(0, 0, 0); h.material_id = 0; h.portal_id = 0;
+    h.has_hit = false; h.position = F3(0, 0, 0); h.normal = F3(0, 0, 0); h.material_id = 0; h.portal_id = 0; h.kind = RT_HIT_MISS; h.slot = 0; h.t = closest;
     if (!is_inf(p1) && p1 < p2) {
         h.has_hit = true; h.position = r.pos + r.dir * p1; h.normal = pd1; h.portal_id = 1;
-        if (tap) { tap->kind = RT_HIT_PORTAL_1; tap->slot = 0; tap->t = p1; }
+        h.kind = RT_HIT_PORTAL_1; h.t = p1;
         return h;
     }
     if (!is_inf(p2) && p2 < p1) {
         h.has_hit = true; h.position = r.pos + r.dir * p2; h.normal = pd2; h.portal_id = 2;
-        if (tap) { tap->kind = RT_HIT_PORTAL_2; tap->slot = 0; tap->t = p2; }
+        h.kind = RT_HIT_PORTAL_2; h.t = p2;
         return h;
     }
     if (is_inf(closest)) {
-        if (tap) { tap->kind = RT_HIT_MISS; tap->slot = 0; tap->t = closest; }
         return h;
     }
     h.has_hit = true;
     h.position = r.pos + r.dir * closest;
     if (cyl_hit) {
         h.normal = cyl_n;
-        if (tap) { tap->kind = RT_HIT_CYLINDER; tap->slot = 0; tap->t = closest; }
+        h.kind = RT_HIT_CYLINDER;
     } else if (tri_hit) {
         const float4 *sr = reinterpret_cast<const float4 *>(S.shade + closest_tri);      // frag:541-549 from one record
         const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
@@ -989,12 +987,12 @@ DEVI Hit finish_intersection(const RtDeviceScene &S, const rt_uniforms &U, const
         h.normal = (F3(q2.y, q2.z, q2.w) * uvw.x + F3(q3.x, q3.y, q3.z) * uvw.y) + F3(q3.w, q4.x, q4.y) * uvw.z;
         h.material_id = f2u(q4.z);
         if (COUNT) cn.tri_shaded++;
-        if (tap) { tap->kind = RT_HIT_TRIANGLE; tap->slot = closest_tri; tap->t = closest; }
+        h.kind = RT_HIT_TRIANGLE; h.slot = closest_tri;
     } else {
         const float4 s = c_spheres[closest_i];
         h.normal = normalize3(h.position - F3(s.x, s.y, s.z));
         h.material_id = closest_i % 7u;
-        if (tap) { tap->kind = RT_HIT_SPHERE; tap->slot = closest_i; tap->t = closest; }
+        h.kind = RT_HIT_SPHERE; h.slot = closest_i;
     }
     return h;
 }
@@ -1356,16 +1354,15 @@ DEVI void render_body(const RtDeviceScene &S, const RtLaunch &L, const RtBatch *
                 st.reset_to_root(key);
                 while (!st.empty()) visit_node<COUNT>(S, ray, st, key, near_first, closest, closest_tri, tri_hit, cn);
             }
-            PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
-            const Hit h = finish_intersection<COUNT>(S, U, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, i == 0 ? &tap : nullptr, cn);
+            const Hit h = finish_intersection<COUNT>(S, U, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, cn);
             nrays++;
             if (i == 0) {   // the first segment's planes are stored at once instead of being carried through the path
                 const uint32_t pix = opaque((uint32_t)p.pi);   // (addresses formed here, not ahead of the loop)
                 if (BATCH && frame + 1u != B->n) { /* the planes keep the last frame's values */ } else {
                 if (L.depth) L.depth[pix] = first_hit_depth(U, h, ray);
-                if (L.hit_kind) L.hit_kind[pix] = tap.kind;
-                if (L.hit_slot) L.hit_slot[pix] = tap.slot;
-                if (L.hit_t) L.hit_t[pix] = tap.t;
+                if (L.hit_kind) L.hit_kind[pix] = h.kind;
+                if (L.hit_slot) L.hit_slot[pix] = h.slot;
+                if (L.hit_t) L.hit_t[pix] = h.t;
                 }
             }
             if (!h.has_hit) { color = color * sample_sky(S, ray.dir); break; }
@@ -1713,13 +1710,12 @@ __global__ __launch_bounds__(256) void shade_kernel(RtDeviceScene S, RtLaunch L,
                 const uint32_t closest_i = WS.sphere[slot];
                 const uint32_t tri_word = WS.tri[slot];
                 if (COUNT) cn.rays++;
-                PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
-                const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, tri_word & 0x7FFFFFFFu, (tri_word >> 31) != 0, D0 ? &tap : nullptr, cn);
+                const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, tri_word & 0x7FFFFFFFu, (tri_word >> 31) != 0, cn);
                 if (D0) {
                     if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
-                    if (L.hit_kind) L.hit_kind[pix] = tap.kind;
-                    if (L.hit_slot) L.hit_slot[pix] = tap.slot;
-                    if (L.hit_t) L.hit_t[pix] = tap.t;
+                    if (L.hit_kind) L.hit_kind[pix] = h.kind;
+                    if (L.hit_slot) L.hit_slot[pix] = h.slot;
+                    if (L.hit_t) L.hit_t[pix] = h.t;
                 }
                 bool done = false;
                 if (!h.has_hit) {
@@ -1863,13 +1859,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEVELS <= 2
         const uint32_t refill = unit < n_units ? PATH_REFILL : 1u;
         if (work != 0 && (trav == 0 || (uint32_t)__popcll(work) >= refill)) {
             if (has_path && !traversing) {   // the segment's intersection is complete (frag:535-563,575-664)
-                PrimaryTap tap = {RT_HIT_MISS, 0, __builtin_inff()};
-                const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, seg == 0 ? &tap : nullptr, cn);
+                const Hit h = finish_intersection<COUNT>(S, L.u, lds_portals, ray, closest, closest_i, closest_tri, tri_hit, cn);
                 if (seg == 0) {
                     if (L.depth) L.depth[pix] = first_hit_depth(L.u, h, ray);
-                    if (L.hit_kind) L.hit_kind[pix] = tap.kind;
-                    if (L.hit_slot) L.hit_slot[pix] = tap.slot;
-                    if (L.hit_t) L.hit_t[pix] = tap.t;
+                    if (L.hit_kind) L.hit_kind[pix] = h.kind;
+                    if (L.hit_slot) L.hit_slot[pix] = h.slot;
+                    if (L.hit_t) L.hit_t[pix] = h.t;
                 }
                 seg++;
                 bool done;
