@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--scene", default="bunny", choices=["bunny", "synthetic_100k", "synthetic_1m"])
     ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront", "megakernel"])
     ap.add_argument("--subframes", type=int, default=None)
+    ap.add_argument("--frames-in-flight", type=int, default=None, help="frames of a sequence traced concurrently (default: the library's choice)")
     ap.add_argument("--per-frame-calls", action="store_true", help="one rt_render per step instead of rt_render_sequence calls")
     ap.add_argument("--present-every", type=int, default=0,
                     help="N > 1: the accumulated frame is gathered to rank 0 after every this many steps and after the last one. "
@@ -286,6 +287,8 @@ def main():
         sc.set_traversal_order(traversal)
         if args.subframes:
             sc.set_subframes(args.subframes)
+        if args.frames_in_flight:
+            sc.set_frames_in_flight(args.frames_in_flight)
         t_build = time.time() - t_build
 
         cam = Camera(aspect=W / H)
@@ -383,8 +386,8 @@ def main():
         # ---- wavefront pipeline: the traversal kernel's own duration, with the sub-frames serialised (in the timed frames several
         # sub-frame chains overlap on separate streams, so a launch's event pair also spans time it shared the machine) -----------
         serial = None
-        if pipeline == "wavefront" and (args.subframes or 3) > 1:
-            sc.set_subframes(1)
+        if pipeline == "wavefront":
+            sc.set_subframes(1); sc.set_frames_in_flight(1)
             n_ser = min(steps, 4)
             ser_frames = [frame_of(k, k + 1) for k in range(n_ser)]
             sc.render_sequence_raw(ser_frames[:2], target_of(sync=True))
@@ -396,7 +399,7 @@ def main():
             ser_elapsed = time.perf_counter() - t1
             s_ms, s_n = sc.kernel_time()
             sc.set_kernel_timing(False)
-            sc.set_subframes(args.subframes or 3)
+            sc.set_subframes(args.subframes or 0); sc.set_frames_in_flight(args.frames_in_flight or 0)
             serial = {"frame_ms": 1e3 * ser_elapsed / n_ser, "kernel_ms": s_ms / max(s_n, 1), "launches_per_frame": s_n / n_ser}
 
         # ---- count the work of the timed frames (untimed replay with counters on) ------------------------------

@@ -191,12 +191,22 @@ int rt_scene_set_pipeline(rt_scene *scene, int pipeline);
 /* The pipeline the next frame would run with and, under RT_PIPELINE_AUTO, the per-frame milliseconds measured so far
  * for RT_PIPELINE_MEGAKERNEL / WAVEFRONT / PERSISTENT (index = enum value; negative: not measured yet). */
 int rt_scene_pipeline_state(rt_scene *scene, int *selected, double ms_per_frame[3]);
-/* Persistent and wavefront pipelines: a frame is rendered as up to n (1..8, default 3) interleaved sub-frames (every
- * n-th 16-row strip) whose kernels run on separate internal streams, forked from and joined to rt_frame.stream, so that
- * the sparse end of one sub-frame's kernels overlaps dense work of another (most effective inside rt_render_sequence,
- * where consecutive frames of a sub-frame follow each other without a join).  A sub-frame is never smaller than 2^19
- * pixels.  Results do not depend on n. */
+/* Persistent and wavefront pipelines: a frame is rendered as up to n (1..8) interleaved sub-frames (every n-th 16-row
+ * strip) whose kernels run on separate internal streams, forked from and joined to rt_frame.stream, so that the sparse
+ * end of one sub-frame's kernels overlaps dense work of another.  A sub-frame is never smaller than 2^19 pixels.
+ * n = 0 (the default) leaves the number to the library: 3 for a single frame, 1 where a sequence can keep frames in
+ * flight instead (see below).  Results do not depend on n. */
 int rt_scene_set_subframes(rt_scene *scene, int n);
+/* Persistent and wavefront pipelines inside rt_render_sequence: n (1..8) consecutive frames of the sequence are traced
+ * concurrently, each on an internal stream and in a workspace of its own (about 112 bytes per pixel of the share for the
+ * wavefront pipeline) into a staging plane (16 bytes per pixel and frame in flight); their samples are blended into the
+ * target strictly in frame order, so the target holds exactly what frame-after-frame rendering leaves in it, and the other
+ * planes hold the last frame's values.  Unlike sub-frames this overlaps kernels without shrinking them and also works
+ * when the share is small (one of several ranks' bands, a 720p frame).  n = 0 (the default) leaves the number to the
+ * library: 3 unless sub-frames were asked for.  Applies to sequences whose every frame has max_recursion_limit >= 1 and
+ * whose target is compact or covers the whole frame; sub-frames times frames in flight is at most 8.
+ * No counterpart in the reference, which submits one draw per frame (App.cpp:95-111). */
+int rt_scene_set_frames_in_flight(rt_scene *scene, int n);
 /* One-kernel-per-frame pipeline inside rt_render_sequence: when a launch covers only a small part of a 4K frame (one
  * rank's bands, a small window), up to max_frames (2..8) consecutive frames are traced by one launch -- their samples
  * are independent -- and blended into the target in frame order by a second small kernel; the pixels are the same.

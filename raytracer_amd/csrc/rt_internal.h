@@ -185,6 +185,8 @@ int rt_build_scene_records(const float *vertices, const float *normals, const ui
                            uint32_t *dup_parent, RtTriRec **risky, uint32_t *n_risky);
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
 size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
+// blends a staged sample plane (compact layout of the share) into launch.color with the launch's accum_index / blend
+int rt_launch_blend(const RtLaunch &launch, const float4 *stage, void *stream);
 // pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:
 // one-lane-per-pixel kernel; otherwise the per-depth wavefront pipeline.
 int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, uint32_t *pool, void *stream, const char **err, RtProbe *probe = nullptr,

@@ -2032,6 +2032,27 @@ size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows) {
 }
 size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows) { return rt_workspace_ranges(width, n_local_rows) * RANGE; }
 
+namespace {
+// Blends one staged sample plane (laid out like a compact target of the rank's share) into the colour target: the launch's
+// accum_index and blend state, applied to the pixels of the launch's sub-frame (App.cpp:49,102-105).
+__global__ __launch_bounds__(256) void blend_stage_kernel(RtLaunch L, const float4 *__restrict__ stage) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= L.width * L.n_local_rows) return;
+    const uint32_t x = i % L.width, lr = i / L.width;
+    const uint32_t y = ((lr / L.band_rows) * L.band_parts + L.band_part) * L.band_rows + (lr % L.band_rows);
+    if (y >= L.height) return;
+    const uint32_t part_lr = ((lr / L.band_rows) * L.sub_parts + L.sub_part) * L.band_rows + (lr % L.band_rows);
+    const float4 c = stage[(size_t)part_lr * L.width + x];
+    write_pixel(L, L.compact_rows ? (size_t)part_lr * L.width + x : (size_t)y * L.width + x, F3(c.x, c.y, c.z));
+}
+}
+int rt_launch_blend(const RtLaunch &L, const float4 *stage, void *stream) {
+    const uint32_t px = L.width * L.n_local_rows;
+    if (px == 0) return 0;
+    hipLaunchKernelGGL(blend_stage_kernel, dim3((px + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, L, stage);
+    return (int)hipGetLastError();
+}
+
 int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L_in, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe, const RtBatch *batch) {
     RtLaunch L = L_in;
     L.eye_count = nullptr; L.eye_list = nullptr;

@@ -2,8 +2,8 @@
     python tests/fuzz_sequences.py [--cases N] [--seed S]
 
 Each case draws a frame size (1..400 x 1..300), a sequence of 1..14 frames (own time, recursion limit and blend flag per
-frame), a band split (strip height, parts, part, compact or full-frame addressing), a pipeline, a sub-frame count and a
-batch setting, renders the sequence with ONE rt_render_sequence call into host planes pre-filled with a pattern, and
+frame), a band split (strip height, parts, part, compact or full-frame addressing), a pipeline, a sub-frame count, a number
+of frames in flight and a batch setting, renders the sequence with ONE rt_render_sequence call into host planes pre-filled with a pattern, and
 compares colour, depth and the primary-hit planes bit for bit with the CPU oracle's frame-by-frame accumulation of the
 same rows; rows the band part does not own must keep the pattern."""
 import argparse
@@ -26,6 +26,7 @@ def main():
     from raytracer_amd.camera import Camera
     from raytracer_amd.params import Uniforms
     rng = np.random.default_rng(a.seed)
+    rng_flight = np.random.default_rng(a.seed + 10007)       # (a generator of its own: the cases of a seed stay what they were)
     oc = scenes.default_octree()
     sky = rng.integers(0, 256, size=(6, 32, 32, 4), dtype=np.uint8)
     osc = oracle.OracleScene(oc.as_dict(), sky)
@@ -53,7 +54,8 @@ def main():
             lim = base_limit if rng.uniform() < 0.85 else int(rng.integers(0, 7))
             us.append(Uniforms.from_camera(cam, time=float(rng.uniform(0, 50)), max_recursion_limit=lim).pack())
             blends.append(bool(rng.uniform() < 0.85))
-        sc.set_pipeline(pipe); sc.set_subframes(sub); sc.set_sequence_batch(batch)
+        flight = int(rng_flight.choice([0, 0, 1, 2, 3, 4, 8]))
+        sc.set_pipeline(pipe); sc.set_subframes(sub); sc.set_frames_in_flight(flight); sc.set_sequence_batch(batch)
         frames = [api.make_frame(us[k], w, h, accum_index=start + k, blend=blends[k], band=(band_rows, parts, part), compact=compact) for k in range(n)]
         rows = api.band_row_count(frames[0]) if compact else h
         ys = rdist.local_to_frame_rows(h, band_rows, parts, part)                 # frame row of every local row (-1: beyond the frame)
@@ -88,7 +90,7 @@ def main():
                 diffs[key] = (d, "foreign rows touched" if not rest_ok else "")
         if diffs:
             bad += 1
-            print(f"MISMATCH case {case} seed {a.seed}: {w}x{h} n={n} band=({band_rows},{parts},{part}) compact={compact} pipe={pipe} sub={sub} batch={batch} start={start} "
+            print(f"MISMATCH case {case} seed {a.seed}: {w}x{h} n={n} band=({band_rows},{parts},{part}) compact={compact} pipe={pipe} sub={sub} flight={flight} batch={batch} start={start} "
                   f"limits={[int(u[19:20].view(np.uint32)[0]) for u in us]} blends={[int(b) for b in blends]}: {diffs}", flush=True)
         if case % 20 == 19:
             print(f"{case + 1} cases, {bad} mismatching", flush=True)

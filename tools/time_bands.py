@@ -15,6 +15,8 @@ NAME = sys.argv[1] if len(sys.argv) > 1 else "bunny"
 LIMIT = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 sc = api.Scene.from_dict({"bunny": scenes.default_octree, "s100k": scenes.synthetic_100k, "s1m": scenes.synthetic_1m}[NAME](device=0).as_dict()); sc.set_skybox(scenes.procedural_skybox(900))
 sc.set_sequence_batch(MAX_BATCH)
+if os.environ.get("RT_TIME_BANDS_CHAINS"):      # "sub-frames,frames in flight"
+    k, fl = map(int, os.environ["RT_TIME_BANDS_CHAINS"].split(",")); sc.set_subframes(k); sc.set_frames_in_flight(fl)
 for parts in (1, 2, 4, 8):
     rows = rdist.padded_row_count(H, 16, parts) if parts > 1 else H
     color = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
