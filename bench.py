@@ -534,7 +534,7 @@ def main():
         for name, scene_name, order in subs:
             if (args.scene, args.max_recursion_limit) == (scene_name, 5):
                 continue
-            ns = run_workload(name, scene_name, 5, max(4, min(args.steps, 12)), min(args.warmup, 2), cpu_leg=False, traversal=order)
+            ns = run_workload(name, scene_name, 5, max(4, min(args.steps, 20)), min(args.warmup, 2), cpu_leg=False, traversal=order)
             cfg = ns.pop("config")
             ns.update({k: cfg[k] for k in ("scene", "pipeline", "traversal_order", "selected_by", "candidates_ms")})
             ns.pop("valu", None)
