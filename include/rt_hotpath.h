@@ -142,9 +142,10 @@ int rt_render(rt_scene *scene, const rt_frame *frame, const rt_target *target);
  * App.cpp:103-140, blending 1/n at ray_tracer.frag:655-656) as one call: renders frames[0..n_frames) in order into
  * the same target; pixel values are identical to n_frames rt_render calls.  All frames must agree in width, height,
  * band selection, compact_rows, ndc tables and stream; uniforms, accum_index and blend may differ.  With the
- * wavefront pipeline and more than one sub-frame the sub-frame chains of consecutive frames are pipelined (a pixel's
- * frames stay ordered), which a caller issuing one rt_render per frame on one stream cannot get.  Host-memory
- * targets are uploaded once before and downloaded once after the sequence. */
+ * wavefront and persistent pipelines consecutive frames are traced concurrently on internal streams and blended in
+ * frame order (rt_scene_set_frames_in_flight; with sub-frames, their chains are pipelined across frames), which a
+ * caller issuing one rt_render per frame on one stream cannot get; a pixel's frames stay ordered either way.
+ * Host-memory targets are uploaded once before and downloaded once after the sequence. */
 int rt_render_sequence(rt_scene *scene, const rt_frame *frames, size_t n_frames, const rt_target *target);
 /* No counterpart in the reference.  For callers that cannot allocate device memory while they render -- code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc: rt_render with the one-kernel pipeline
