@@ -208,6 +208,14 @@ int rt_scene_set_subframes(rt_scene *scene, int n);
  * whose target is compact or covers the whole frame; sub-frames times frames in flight is at most 8.
  * No counterpart in the reference, which submits one draw per frame (App.cpp:95-111). */
 int rt_scene_set_frames_in_flight(rt_scene *scene, int n);
+/* Wavefront pipeline inside rt_render_sequence, together with frames in flight: up to n (1..8) consecutive frames that differ
+ * in rt_uniforms.time only -- the samples of a still camera (App.cpp:103-140) -- are traced by ONE chain of launches n times
+ * as large: time only enters ray generation (ray_tracer.frag:679), so the first kernel generates the paths of all n frames
+ * and the others run unchanged on a queue n times as long, whose sparse end the n frames share.  Samples go to a staging
+ * plane per frame and are blended in frame order as above; results are identical.  n = 0 (the default) leaves the number
+ * to the library (8, at most 2^25 paths per chain: 4 at 4K).  Not used when the target has planes besides colour.
+ * No counterpart in the reference. */
+int rt_scene_set_frames_per_launch(rt_scene *scene, int n);
 /* One-kernel-per-frame pipeline inside rt_render_sequence: when a launch covers only a small part of a 4K frame (one
  * rank's bands, a small window), up to max_frames (2..8) consecutive frames are traced by one launch -- their samples
  * are independent -- and blended into the target in frame order by a second small kernel; the pixels are the same.

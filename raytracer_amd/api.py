@@ -29,7 +29,7 @@ HIT_MISS, HIT_SPHERE, HIT_TRIANGLE, HIT_CYLINDER, HIT_PORTAL_1, HIT_PORTAL_2 = r
 
 EXPORTED_SYMBOLS = [
     "rt_last_error", "rt_build_id", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_skybox_set", "rt_render", "rt_render_sequence", "rt_render_noalloc", "rt_band_row_count", "rt_scene_stats",
-    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_frames_in_flight", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_selection_state", "rt_scene_last_mode", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free", "rt_scene_create_from_meshes",
+    "rt_scene_set_counting", "rt_scene_set_kernel_timing", "rt_scene_kernel_time", "rt_scene_set_pipeline", "rt_scene_pipeline_state", "rt_scene_set_subframes", "rt_scene_set_frames_in_flight", "rt_scene_set_frames_per_launch", "rt_scene_set_sequence_batch", "rt_scene_set_traversal_order", "rt_scene_selection_state", "rt_scene_last_mode", "rt_scene_destroy", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_mesh_free", "rt_octree_build", "rt_octree_build_device", "rt_octree_free", "rt_scene_create_from_meshes",
     # include/rt_camera.h (bound in glm_camera.py)
     "rt_vec3_normalize", "rt_camera_init", "rt_camera_set_view", "rt_camera_set_proj", "rt_camera_view_proj", "rt_camera_inv_view_proj", "rt_portal_difference_matrix", "rt_portal_ray",
     "rt_manipulator_init", "rt_manipulator_set_camera", "rt_manipulator_update", "rt_manipulator_key", "rt_manipulator_mouse_move", "rt_manipulator_mouse_wheel",
@@ -120,6 +120,7 @@ def lib():
         L.rt_scene_pipeline_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.rt_scene_set_subframes.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_set_frames_in_flight.argtypes = [C.c_void_p, C.c_int]
+        L.rt_scene_set_frames_per_launch.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_set_sequence_batch.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_set_traversal_order.argtypes = [C.c_void_p, C.c_int]
         L.rt_scene_selection_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -501,6 +502,9 @@ class Scene:
 
     def set_frames_in_flight(self, n: int):
         _check(lib().rt_scene_set_frames_in_flight(self._h, n))
+
+    def set_frames_per_launch(self, n: int):
+        _check(lib().rt_scene_set_frames_per_launch(self._h, n))
 
     def stats(self) -> dict:
         s = rt_stats()

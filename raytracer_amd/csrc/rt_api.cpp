@@ -92,6 +92,7 @@ struct rt_scene {
     int pipeline = RT_PIPELINE_AUTO;
     int subframes = 0;                 // sub-frames per frame (0: the library's choice)
     int frames_in_flight = 0;          // frames of a sequence traced concurrently (0: the library's choice)
+    int frames_per_launch = 0;         // frames of a sequence sharing one chain of wavefront launches (0: the library's choice)
     struct Sub {
         RtWorkspace ws{};
         void *block = nullptr;
@@ -502,6 +503,12 @@ int rt_scene_set_frames_in_flight(rt_scene *s, int n) {
     s->frames_in_flight = n;
     return RT_OK;
 }
+int rt_scene_set_frames_per_launch(rt_scene *s, int n) {
+    if (!s) return fail(RT_EINVAL, "scene is NULL");
+    if (n < 0 || n > RT_MAX_STACK) return fail(RT_EINVAL, "frames per launch must be in [0,%d]", RT_MAX_STACK);
+    s->frames_per_launch = n;
+    return RT_OK;
+}
 int rt_scene_set_subframes(rt_scene *s, int n) {
     if (!s) return fail(RT_EINVAL, "scene is null");
     if (n < 0 || n > RT_MAX_SUBFRAMES) return fail(RT_EINVAL, "subframes must be in [0,%d]", RT_MAX_SUBFRAMES);
@@ -704,7 +711,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
     // through the one-kernel pipeline whatever was chosen
     if (measure && (pipeline != RT_PIPELINE_MEGAKERNEL) && (min_limit < 1 || !(wavefront || persistent))) measure = false;
     // sub-frames per frame (every one should still fill the machine: >= 2^19 pixels) and frames in flight
-    uint32_t K = 1, F = 1;
+    uint32_t K = 1, F = 1, V = 1;
     // (the one-kernel-per-frame pipeline orders its workgroups by measured cost instead, see attach_order: with that its
     // kernels end without a sparse tail and sub-frames bring it nothing)
     if (wavefront || persistent) {
@@ -725,13 +732,26 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         if (can_fly) {
             F = s->frames_in_flight > 0 ? (uint32_t)s->frames_in_flight : (K == 1 ? 3u : 1u);
             F = std::max<uint32_t>(1u, std::min<uint32_t>(F, (uint32_t)std::min<size_t>(n_frames, RT_MAX_SUBFRAMES / K)));
+            // Consecutive frames that differ in `time` only (the samples of a still camera) can also share their launches
+            // (RtStack): V of them are traced by one chain of kernels V times as large.  Not when the caller wants the
+            // other planes (their pixels are addressed through the target's own layout), and at most 2^25 slots per
+            // chain, the size of an 8K frame.
+            const bool planes = t->depth || t->hit_kind || t->hit_slot || t->hit_t || t->n_rays;
+            if (wavefront && F > 1 && !planes) {
+                rt_frame fj = *f;
+                fj.band_parts = f->band_parts * K; fj.band_part = f->band_part;
+                const size_t slots = rt_workspace_slots(f->width, band_rows_of(&fj));
+                V = s->frames_per_launch > 0 ? (uint32_t)s->frames_per_launch : RT_MAX_STACK;
+                while (V > 1 && slots * V > ((size_t)1 << 25)) V--;
+                V = std::min<uint32_t>(V, (uint32_t)((n_frames + F - 1) / F));   // (every chain should get a group)
+            }
         }
         for (uint32_t j = 0; j < K * F; j++) {   // chain j = (frame mod F) * K + sub-frame
             rt_frame fj = *f;
             fj.band_parts = f->band_parts * K; fj.band_part = (j % K) * f->band_parts + f->band_part;
             const uint32_t rows = band_rows_of(&fj);
             if (wavefront) {
-                int wrc = ensure_workspace(s, &s->sub[j], rt_workspace_slots(f->width, rows), rt_workspace_ranges(f->width, rows));
+                int wrc = ensure_workspace(s, &s->sub[j], rt_workspace_slots(f->width, rows, V), rt_workspace_ranges(f->width, rows, V));
                 if (wrc != RT_OK && j >= K) {   // no memory for another frame in flight: fewer of them
                     (void)hipGetLastError();
                     F = j / K;
@@ -743,7 +763,7 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
                     if (s->pipeline != RT_PIPELINE_AUTO) return wrc;
                     for (int c = 0; c < RT_N_CAND; c++) if (kCandPipeline[c] == RT_PIPELINE_WAVEFRONT) { s->tuner.tab[s->tuner.cur].ms[c] = 1e30; s->tuner.tab[s->tuner.cur].seen[c] = 2; }
                     (void)hipGetLastError();   // (the failed allocation's error is handled here)
-                    wavefront = false; measure = false; pipeline = RT_PIPELINE_MEGAKERNEL; cand = 0; K = 1; F = 1;
+                    wavefront = false; measure = false; pipeline = RT_PIPELINE_MEGAKERNEL; cand = 0; K = 1; F = 1; V = 1;
                     L.near_first = (uint32_t)candidate_order(s, 0);
                     break;
                 }
@@ -758,17 +778,19 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
         if ((K > 1 || F > 1) && !s->fork_ev) HIP_TRY(hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
         if (F > 1) {
             const size_t spx = (size_t)f->width * L.n_local_rows;
-            if (s->stage_elems < F * spx) {
+            if (s->stage_elems < (size_t)F * V * spx) {
                 if (s->stage) { s->retired.push_back(s->stage); s->stage = nullptr; s->stage_elems = 0; }
-                if (hipMalloc(&s->stage, F * spx * 16) != hipSuccess) { (void)hipGetLastError(); F = 1; }
-                else s->stage_elems = F * spx;
+                if (hipMalloc(&s->stage, (size_t)F * V * spx * 16) != hipSuccess) { (void)hipGetLastError(); F = 1; V = 1; }
+                else s->stage_elems = (size_t)F * V * spx;
             }
         }
     }
-    // Enqueues the sequence.  Single-kernel pipeline or one sub-frame: frame after frame on the caller's stream.
-    // Otherwise K sub-frame chains are forked from the caller's stream once, each runs its share of every frame
-    // in order on its own stream (a pixel belongs to one sub-frame, so its accumulation order is kept), and all
-    // are joined back once: the chains drift apart and the sparse end of one kernel overlaps dense work of others.
+    // Enqueues the sequence.  Single-kernel pipeline, or one sub-frame and one frame in flight: frame after frame on the
+    // caller's stream.  Otherwise the K x F chains are forked from the caller's stream once and joined back once.  Without
+    // frames in flight each sub-frame chain runs its share of every frame in order on its own stream and blends into the
+    // target itself (a pixel belongs to one sub-frame, so its accumulation order is kept); with them, chain (i mod F, j)
+    // traces sub-frame j of frame i into staging plane i mod F and blends it after frame i-1's blend of the same sub-frame.
+    // Either way the chains drift apart and the sparse end of one kernel overlaps dense work of others.
     // One-lane-per-pixel launches start their workgroups in the order of the cost (duration) that the previous launch with
     // the same frame geometry measured per workgroup: progressive accumulation renders the same view again and again, and
     // a moving camera changes the cost map only gradually.  The first launch of a geometry uses the order given by the
@@ -856,23 +878,34 @@ static int render_frames(rt_scene *s, const rt_frame *frames, size_t n_frames, c
             const size_t spx = (size_t)f->width * L0.n_local_rows;
             if (hipEventRecord(s->fork_ev, st) != hipSuccess) return 1;
             for (uint32_t c = 0; c < K * F; c++) if (hipStreamWaitEvent(s->sub[c].stream, s->fork_ev, 0) != hipSuccess) return 1;
-            for (size_t i = 0; i < n_frames; i++) {
-                const uint32_t phase = (uint32_t)(i % F), before = (phase + F - 1u) % F;
+            auto same_view = [](rt_uniforms a, rt_uniforms b) { a.time = 0.0f; b.time = 0.0f; return memcmp(&a, &b, sizeof a) == 0; };
+            size_t i = 0;
+            for (uint32_t group = 0; i < n_frames; group++) {
+                const uint32_t phase = group % F, before = (phase + F - 1u) % F;
+                RtStack G{};
+                G.stride = (uint32_t)spx;
+                while (G.n < V && i + G.n < n_frames && (G.n == 0 || same_view(frames[i].u, frames[i + G.n].u))) {
+                    G.time[G.n] = frames[i + G.n].u.time; G.accum_index[G.n] = frames[i + G.n].accum_index; G.blend[G.n] = frames[i + G.n].blend ? 1u : 0u;
+                    G.n++;
+                }
+                const float4 *planes = (const float4 *)s->stage + (size_t)phase * V * spx;
                 for (uint32_t j = 0; j < K; j++) {
                     RtLaunch Li = frame_launch(i, K, j);
                     if (Li.n_local_rows == 0) continue;
                     rt_scene::Sub &sb = s->sub[phase * K + j];
                     RtLaunch Lb = Li;                                   // the blend into the target
                     Lb.color = L0.color;
-                    Li.color = (float *)((float4 *)s->stage + (size_t)phase * spx); Li.compact_rows = 1; Li.blend = 0; Li.accum_index = 1;
+                    Li.color = (float *)planes; Li.compact_rows = 1; Li.blend = 0; Li.accum_index = 1;
                     // the other planes hold what the last frame of the sequence leaves in them
-                    if (i + 1 < n_frames) { Li.depth = nullptr; Li.hit_kind = nullptr; Li.hit_slot = nullptr; Li.hit_t = nullptr; Li.n_rays = nullptr; }
-                    int rc = rt_launch_render(s->d, Li, wavefront ? &sb.ws : nullptr, persistent ? sb.pool : nullptr, sb.stream, kerr, s->timing ? &sb.probe : nullptr);
+                    if (i + G.n < n_frames) { Li.depth = nullptr; Li.hit_kind = nullptr; Li.hit_slot = nullptr; Li.hit_t = nullptr; Li.n_rays = nullptr; }
+                    int rc = rt_launch_render(s->d, Li, wavefront ? &sb.ws : nullptr, persistent ? sb.pool : nullptr, sb.stream, kerr, s->timing ? &sb.probe : nullptr, nullptr,
+                                              wavefront ? &G : nullptr);
                     if (rc != 0) return rc;
-                    if (i > 0 && hipStreamWaitEvent(sb.stream, s->sub[before * K + j].done, 0) != hipSuccess) return 1;
-                    if (rt_launch_blend(Lb, (const float4 *)s->stage + (size_t)phase * spx, sb.stream) != 0) return 1;
+                    if (group > 0 && hipStreamWaitEvent(sb.stream, s->sub[before * K + j].done, 0) != hipSuccess) return 1;
+                    if (rt_launch_blend(Lb, planes, G, sb.stream) != 0) return 1;
                     if (hipEventRecord(sb.done, sb.stream) != hipSuccess) return 1;
                 }
+                i += G.n;
             }
             for (uint32_t c = 0; c < K * F; c++) {
                 // (a chain without rows has recorded nothing; waiting for a never-recorded event returns at once)

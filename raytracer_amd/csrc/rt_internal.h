@@ -150,6 +150,18 @@ struct RtBatch {
     float4 *stage;
 };
 
+// Several consecutive frames of a sequence traced by ONE chain of wavefront launches.  The frames share everything but `time`
+// (consecutive samples of a still camera, App.cpp:103-140), which only enters ray generation (frag:679): the first kernel of the
+// chain generates n x the frame's paths, those of frame f addressed to staging plane f, and every later kernel runs unchanged on
+// a queue n times as long -- the sparse end of a launch is shared by n frames.  The planes are blended in frame order afterwards.
+#define RT_MAX_STACK 8
+struct RtStack {
+    uint32_t n;                 // frames (1..RT_MAX_STACK)
+    uint32_t stride;            // pixels per staging plane (= width x rows of the rank's share)
+    float time[RT_MAX_STACK];
+    uint32_t accum_index[RT_MAX_STACK], blend[RT_MAX_STACK];
+};
+
 // Optional timing of the dominant kernel (the traversal kernel of the wavefront pipeline, the single kernel of the
 // other): pairs of HIP events recorded on the launch stream directly before and after each such launch.
 struct RtProbe {
@@ -183,14 +195,15 @@ int rt_build_node_records(const uint32_t *d_words, size_t n_words, size_t n_ref,
 // risky / n_risky: see RtDeviceScene (*risky is hipMalloc'ed when *n_risky is in 1..RT_MAX_RISKY; the caller frees).
 int rt_build_scene_records(const float *vertices, const float *normals, const uint32_t *tri_refs, uint32_t n_ref, RtNodeRec *nodes, uint32_t n_nodes, RtTriRec *tris, RtShadeRec *shade,
                            uint32_t *dup_parent, RtTriRec **risky, uint32_t *n_risky);
-size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows);
-size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows);
-// blends a staged sample plane (compact layout of the share) into launch.color with the launch's accum_index / blend
-int rt_launch_blend(const RtLaunch &launch, const float4 *stage, void *stream);
+size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows, uint32_t stack = 1);    // stack: frames traced by one chain of launches (RtStack)
+size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows, uint32_t stack = 1);
+// blends the staged sample planes of a stack (compact layout of the share) into launch.color, frame after frame
+int rt_launch_blend(const RtLaunch &launch, const float4 *stage, const RtStack &stack, void *stream);
 // pool != nullptr: persistent path kernel (pool: rt_pool_bytes() of device memory, zeroed by the launch); else workspace == nullptr:
 // one-lane-per-pixel kernel; otherwise the per-depth wavefront pipeline.
 int rt_launch_render(const RtDeviceScene &scene, const RtLaunch &launch, const RtWorkspace *workspace, uint32_t *pool, void *stream, const char **err, RtProbe *probe = nullptr,
-                     const RtBatch *batch = nullptr);   // batch: one-lane-per-pixel pipeline only; launch.u / accum_index / blend are then ignored
+                     const RtBatch *batch = nullptr,    // batch: one-lane-per-pixel pipeline only; launch.u / accum_index / blend are then ignored
+                     const RtStack *stack = nullptr);   // stack: wavefront pipeline only; launch.color is then stack->n staging planes, blend off
 
 // rt_api.cpp, for rt_dist.cpp: scene / skybox creation from arrays that are already in device memory (sent by the root rank), the
 // library's error slot, a scene's device.

@@ -1201,13 +1201,6 @@ DEVI uint32_t xcd_contiguous(uint32_t raw, uint32_t n) {
     const uint32_t q = n / 8u, rem = n % 8u, cls = raw % 8u, idx = raw / 8u;
     return (cls < rem ? cls * (q + 1u) : rem * (q + 1u) + (cls - rem) * q) + idx;
 }
-// Pixel of thread `tid` of workgroup `wg_raw` when every 16x16 tile is shared by `per_tile` workgroups of 256 / per_tile threads.
-DEVI PixelId pixel_of(const RtLaunch &L, uint32_t wg_raw, uint32_t tid, uint32_t per_tile = 1u) {
-    const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
-    const uint32_t v = xcd_contiguous(wg_raw, tiles_x * tiles_y * per_tile);
-    const uint32_t tile = v / per_tile;
-    return pixel_of_tile(L, tile % tiles_x, tile / tiles_x, (v % per_tile) * (256u / per_tile) + tid);
-}
 // Tile order of the one-lane-per-pixel and the persistent path kernel: the tiles of the rectangle L.hot (where the octree projects to: the
 // pixels whose paths can be long) come first, then the rows below it, the rows above it, and the tiles left and right
 // of it, so that the expensive paths start early and the frame ends on cheap ones.  k -> (tile_x, tile_y), bijective.
@@ -1519,7 +1512,10 @@ __global__ void primary_sphere_kernel(RtLaunch L, float4 *__restrict__ prim) {
 }
 
 // The first segment of every path of the frame: ray generation, the sphere loop, the root box test.
-__global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t n_tiles) {
+// With a stack of G.n frames (same view, own `time` each: consecutive samples of a progressive accumulation) the launch covers
+// G.n x the frame's tiles; the paths of frame f carry the pixel index of staging plane f, and nothing after this kernel knows
+// that they belong to different frames.
+__global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch L, RtWorkspace WS, uint32_t n_tiles, RtStack G) {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t lds_base;
     __shared__ uint32_t lds_q[RANGE];
@@ -1535,7 +1531,10 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
     uint32_t n_sph = 0;
     for (uint32_t off = 0; off < count; off += 256u) {
         const uint32_t slot = lo + off + threadIdx.x;
-        const PixelId p = pixel_of(L, blockIdx.x * (RANGE / 256u) + off / 256u, threadIdx.x);
+        const uint32_t tiles_x = (L.width + 15u) / 16u, frame_tiles = n_tiles / G.n;
+        const uint32_t v = xcd_contiguous(blockIdx.x * (RANGE / 256u) + off / 256u, n_tiles), stacked = v / frame_tiles, tile = v % frame_tiles;
+        PixelId p = pixel_of_tile(L, tile % tiles_x, tile / tiles_x, threadIdx.x);
+        p.pi += (size_t)stacked * G.stride;
         const bool valid = p.active;
         Ray ray;
         float closest = __builtin_inff();
@@ -1547,7 +1546,9 @@ __global__ __launch_bounds__(256) void spheres_kernel(RtDeviceScene S, RtLaunch 
         if (valid) {
             float nx, ny;
             pixel_ndc(L, p, nx, ny);
-            generate_ray(L.u, nx, ny, ray.dir, seed_base);
+            rt_uniforms U = L.u;
+            U.time = G.time[stacked];
+            generate_ray(U, nx, ny, ray.dir, seed_base);
         }
         A[slot] = make_float4(ray.pos.x, ray.pos.y, ray.pos.z, seed_base);
         B[slot] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, u2f(valid ? (uint32_t)p.pi : 0xFFFFFFFFu));
@@ -2026,39 +2027,48 @@ int rt_math_check(int op, unsigned long long out[2]) {
 size_t rt_render_units(uint32_t width, uint32_t n_local_rows) {
     return (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u);
 }
-size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows) {
-    const size_t n_tiles = (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u);
+size_t rt_workspace_ranges(uint32_t width, uint32_t n_local_rows, uint32_t stack) {
+    const size_t n_tiles = (size_t)((width + 15u) / 16u) * ((n_local_rows + 15u) / 16u) * stack;
     return (n_tiles + RANGE / 256u - 1) / (RANGE / 256u);
 }
-size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows) { return rt_workspace_ranges(width, n_local_rows) * RANGE; }
+size_t rt_workspace_slots(uint32_t width, uint32_t n_local_rows, uint32_t stack) { return rt_workspace_ranges(width, n_local_rows, stack) * RANGE; }
 
 namespace {
-// Blends one staged sample plane (laid out like a compact target of the rank's share) into the colour target: the launch's
-// accum_index and blend state, applied to the pixels of the launch's sub-frame (App.cpp:49,102-105).
-__global__ __launch_bounds__(256) void blend_stage_kernel(RtLaunch L, const float4 *__restrict__ stage) {
+// Blends the staged sample planes of a stack of frames (each laid out like a compact target of the rank's share, G.stride
+// pixels apart) into the colour target in frame order, with every frame's own accumulation index and blend state, for the
+// pixels of the launch's sub-frame (App.cpp:49,102-105).
+__global__ __launch_bounds__(256) void blend_stage_kernel(RtLaunch L, const float4 *__restrict__ stage, RtStack G) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= L.width * L.n_local_rows) return;
     const uint32_t x = i % L.width, lr = i / L.width;
     const uint32_t y = ((lr / L.band_rows) * L.band_parts + L.band_part) * L.band_rows + (lr % L.band_rows);
     if (y >= L.height) return;
     const uint32_t part_lr = ((lr / L.band_rows) * L.sub_parts + L.sub_part) * L.band_rows + (lr % L.band_rows);
-    const float4 c = stage[(size_t)part_lr * L.width + x];
-    write_pixel(L, L.compact_rows ? (size_t)part_lr * L.width + x : (size_t)y * L.width + x, F3(c.x, c.y, c.z));
+    const size_t si = (size_t)part_lr * L.width + x;
+    float4 *dstp = reinterpret_cast<float4 *>(L.color) + (L.compact_rows ? si : (size_t)y * L.width + x);
+    float4 dst = *dstp;   // (read even when the first frame does not blend: one code path, and the target is mapped memory anyway)
+    for (uint32_t f = 0; f < G.n; f++) {
+        const float4 c = stage[(size_t)f * G.stride + si];
+        dst = blend_sample(dst, F3(c.x, c.y, c.z), G.accum_index[f], G.blend[f]);
+    }
+    *dstp = dst;
 }
 }
-int rt_launch_blend(const RtLaunch &L, const float4 *stage, void *stream) {
+int rt_launch_blend(const RtLaunch &L, const float4 *stage, const RtStack &stack, void *stream) {
     const uint32_t px = L.width * L.n_local_rows;
-    if (px == 0) return 0;
-    hipLaunchKernelGGL(blend_stage_kernel, dim3((px + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, L, stage);
+    if (px == 0 || stack.n == 0) return 0;
+    hipLaunchKernelGGL(blend_stage_kernel, dim3((px + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, L, stage, stack);
     return (int)hipGetLastError();
 }
 
-int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L_in, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe, const RtBatch *batch) {
+int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L_in, const RtWorkspace *WS, uint32_t *pool, void *stream, const char **err, RtProbe *probe, const RtBatch *batch,
+                     const RtStack *stack) {
     RtLaunch L = L_in;
     L.eye_count = nullptr; L.eye_list = nullptr;
     const uint32_t tiles_x = (L.width + 15u) / 16u, tiles_y = (L.n_local_rows + 15u) / 16u;
     if (tiles_x == 0 || tiles_y == 0) return 0;
-    const uint32_t n_tiles = tiles_x * tiles_y;
+    const uint32_t n_tiles = tiles_x * tiles_y, frame_tiles = n_tiles;
+    if (stack && (!WS || stack->n < 1 || stack->n > RT_MAX_STACK)) { if (err) *err = "stacked frames are a feature of the wavefront pipeline"; return 1; }
     hipStream_t st = (hipStream_t)stream;
     // the traversal stack holds at most one entry per tree level (the root's virtual level included)
     const uint32_t need = S.max_depth + 2u;
@@ -2095,7 +2105,11 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L_in, const RtWorks
         if (timed) probe->launches[probe->used++] = 1;
     } else {
         const bool count = L.counters != nullptr;
-        const dim3 grid((uint32_t)rt_workspace_ranges(L.width, L.n_local_rows));   // one workgroup per slot range
+        RtStack G{};
+        if (stack) G = *stack;
+        else { G.n = 1; G.stride = 0; G.time[0] = L.u.time; }
+        const uint32_t n_tiles = frame_tiles * G.n;
+        const dim3 grid((uint32_t)rt_workspace_ranges(L.width, L.n_local_rows, G.n));   // one workgroup per slot range
         const dim3 tgrid((L.n_cu ? L.n_cu : 256u) * TRAVERSE_WG_PER_CU);             // persistent traversal workgroups
         (void)hipMemsetAsync(WS->ctr, 0, 8 * sizeof(uint32_t), st);
         hipLaunchKernelGGL(primary_sphere_kernel, dim3(1), dim3(128), 0, st, L, WS->prim);
@@ -2108,7 +2122,7 @@ int rt_launch_render(const RtDeviceScene &S, const RtLaunch &L_in, const RtWorks
         // whereas asking the device whether any path is left would block the caller inside an enqueue)
         const uint32_t limit = L.u.max_recursion_limit;
         for (uint32_t d = 0; d < limit; d++) {
-            if (d == 0) hipLaunchKernelGGL(spheres_kernel, grid, dim3(256), 0, st, S, L, *WS, n_tiles);    // (later depths: inside the previous shade_kernel)
+            if (d == 0) hipLaunchKernelGGL(spheres_kernel, grid, dim3(256), 0, st, S, L, *WS, n_tiles, G);    // (later depths: inside the previous shade_kernel)
             if (d == 0 && L.eye_count && S.n_nodes) hipLaunchKernelGGL(mark_eye_kernel, dim3(grid.x * (RANGE / 256u)), dim3(256), 0, st, S, L, *WS);
             if (S.n_nodes) {
                 const bool t = timed && probe->used < probe->capacity;

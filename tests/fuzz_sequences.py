@@ -3,7 +3,7 @@
 
 Each case draws a frame size (1..400 x 1..300), a sequence of 1..14 frames (own time, recursion limit and blend flag per
 frame), a band split (strip height, parts, part, compact or full-frame addressing), a pipeline, a sub-frame count, a number
-of frames in flight and a batch setting, renders the sequence with ONE rt_render_sequence call into host planes pre-filled with a pattern, and
+of frames in flight, a number of frames per launch chain, whether colour is the only plane, and a batch setting, renders the sequence with ONE rt_render_sequence call into host planes pre-filled with a pattern, and
 compares colour, depth and the primary-hit planes bit for bit with the CPU oracle's frame-by-frame accumulation of the
 same rows; rows the band part does not own must keep the pattern."""
 import argparse
@@ -55,7 +55,9 @@ def main():
             us.append(Uniforms.from_camera(cam, time=float(rng.uniform(0, 50)), max_recursion_limit=lim).pack())
             blends.append(bool(rng.uniform() < 0.85))
         flight = int(rng_flight.choice([0, 0, 1, 2, 3, 4, 8]))
-        sc.set_pipeline(pipe); sc.set_subframes(sub); sc.set_frames_in_flight(flight); sc.set_sequence_batch(batch)
+        stack = int(rng_flight.choice([0, 0, 1, 2, 3, 8]))
+        color_only = bool(rng_flight.uniform() < 0.5)       # (frames only share launches when colour is the only plane asked for)
+        sc.set_pipeline(pipe); sc.set_subframes(sub); sc.set_frames_in_flight(flight); sc.set_frames_per_launch(stack); sc.set_sequence_batch(batch)
         frames = [api.make_frame(us[k], w, h, accum_index=start + k, blend=blends[k], band=(band_rows, parts, part), compact=compact) for k in range(n)]
         rows = api.band_row_count(frames[0]) if compact else h
         ys = rdist.local_to_frame_rows(h, band_rows, parts, part)                 # frame row of every local row (-1: beyond the frame)
@@ -65,7 +67,11 @@ def main():
                    slot=np.full((rows, w), pattern["slot"], np.uint32), t=np.full((rows, w), pattern["t"], np.float32), nrays=np.full((rows, w), pattern["nrays"], np.uint32))
         tg = api.rt_target()
         tg.memory, tg.sync = api.RT_MEM_HOST, 1
-        tg.color, tg.depth, tg.hit_kind, tg.hit_slot, tg.hit_t, tg.n_rays = (got[k].ctypes.data for k in ("color", "depth", "kind", "slot", "t", "nrays"))
+        tg.color = got["color"].ctypes.data
+        if color_only:
+            got = {"color": got["color"]}
+        else:
+            tg.depth, tg.hit_kind, tg.hit_slot, tg.hit_t, tg.n_rays = (got[k].ctypes.data for k in ("depth", "kind", "slot", "t", "nrays"))
         sc.render_sequence_raw(frames, tg)
         # the oracle, frame by frame over the full frame
         acc = np.full((h, w, 4), pattern["color"], np.float32)
@@ -90,7 +96,7 @@ def main():
                 diffs[key] = (d, "foreign rows touched" if not rest_ok else "")
         if diffs:
             bad += 1
-            print(f"MISMATCH case {case} seed {a.seed}: {w}x{h} n={n} band=({band_rows},{parts},{part}) compact={compact} pipe={pipe} sub={sub} flight={flight} batch={batch} start={start} "
+            print(f"MISMATCH case {case} seed {a.seed}: {w}x{h} n={n} band=({band_rows},{parts},{part}) compact={compact} pipe={pipe} sub={sub} flight={flight} stack={stack} color_only={color_only} batch={batch} start={start} "
                   f"limits={[int(u[19:20].view(np.uint32)[0]) for u in us]} blends={[int(b) for b in blends]}: {diffs}", flush=True)
         if case % 20 == 19:
             print(f"{case + 1} cases, {bad} mismatching", flush=True)

@@ -84,10 +84,45 @@ def test_frames_in_flight_device_target_back_to_back(bunny_octree, test_sky):
     sc.close()
 
 
+def test_stacked_frames_equal_serial_sequence(bunny_octree, test_sky):
+    """Frames that differ in `time` only share one chain of wavefront launches (rt_scene_set_frames_per_launch) when colour is
+    the only plane asked for; runs of such frames are broken by a change of the recursion limit, of the camera, and by the
+    sequence's end."""
+    sc = api.Scene.from_octree(bunny_octree)
+    sc.set_skybox(test_sky)
+    sc.set_pipeline("wavefront")
+    w, h, n = 1000, 600, 13
+    cams = [Camera(aspect=w / h), Camera(eye=(2.5, 1.5, 1.0), at=(0.0, 0.5, 0.0), aspect=w / h)]
+    us = [Uniforms.from_camera(cams[1 if k in (7, 8) else 0], time=0.21 * k, max_recursion_limit=2 if k == 4 else 4).pack() for k in range(n)]
+    blends = [k != 5 for k in range(n)]
+    for band, compact in (((16, 1, 0), False), ((16, 4, 2), True), ((5, 2, 0), True)):
+        frames = [api.make_frame(us[k], w, h, accum_index=3 + k, blend=blends[k], band=band, compact=compact) for k in range(n)]
+        rows = api.band_row_count(frames[0]) if compact else h
+
+        def colour(sub, flight, stack, m=n):
+            sc.set_subframes(sub); sc.set_frames_in_flight(flight); sc.set_frames_per_launch(stack)
+            buf = np.full((rows, w, 4), 0.25, np.float32)
+            tg = api.rt_target()
+            tg.memory, tg.sync, tg.color = api.RT_MEM_HOST, 1, buf.ctypes.data
+            sc.render_sequence_raw(frames[:m], tg)
+            return buf
+
+        want = colour(1, 1, 1)
+        for sub, flight, stack in ((0, 0, 0), (1, 3, 2), (1, 2, 8), (1, 3, 3), (2, 2, 4), (1, 8, 1)):
+            assert np.array_equal(bits(colour(sub, flight, stack)), bits(want)), (band, sub, flight, stack)
+        for m in (2, 3, 5):
+            assert np.array_equal(bits(colour(0, 0, 0, m)), bits(colour(1, 1, 1, m))), (band, m)
+    sc.close()
+
+
 def test_frames_in_flight_argument_range(bunny_octree):
     sc = api.Scene.from_octree(bunny_octree)
     for bad in (-1, 9):
         with pytest.raises(api.RtError):
             sc.set_frames_in_flight(bad)
     sc.set_frames_in_flight(0)
+    for bad in (-1, 9):
+        with pytest.raises(api.RtError):
+            sc.set_frames_per_launch(bad)
+    sc.set_frames_per_launch(0)
     sc.close()
