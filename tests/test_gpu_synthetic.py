@@ -141,6 +141,33 @@ def test_default_settings_run_the_deep_scene_in_the_exact_order_at_4k(synthetic,
     sc.close()
 
 
+def test_4k_sequence_in_flight_and_stacked_equals_frame_after_frame(synthetic, test_sky):
+    """A 4K sequence of the deep scenes as the library issues it by default (chains of frames in flight, consecutive samples
+    sharing their launches) against the same frames traced one after the other on one stream, in both child orders."""
+    import torch
+    name, _, d, _ = synthetic
+    sc = api.Scene.from_dict(d, device=0)
+    sc.set_skybox(test_sky)
+    sc.set_pipeline("wavefront")
+    us = [Uniforms.from_camera(Camera(aspect=W / H), time=k / 60.0, max_recursion_limit=5).pack() for k in range(9)]
+    frames = [api.make_frame(u, W, H, accum_index=k + 1) for k, u in enumerate(us)]
+    color = torch.zeros((H, W, 4), device="cuda")
+    tg = api.rt_target()
+    tg.memory, tg.sync, tg.color = api.RT_MEM_DEVICE, 1, color.data_ptr()
+    results = []
+    for order in ("near_first_exact", "reference"):
+        sc.set_traversal_order(order)
+        for sub, flight, stack in ((1, 1, 1), (0, 0, 0), (1, 2, 4)):
+            sc.set_subframes(sub); sc.set_frames_in_flight(flight); sc.set_frames_per_launch(stack)
+            color.zero_()
+            sc.render_sequence_raw(frames, tg)
+            assert sc.last_mode() == ("wavefront", order)
+            results.append(color.clone())
+    for r in results[1:]:
+        assert torch.equal(r.view(torch.int32), results[0].view(torch.int32)), name
+    sc.close()
+
+
 def test_4k_frames_of_the_synthetic_scenes_match_the_oracle_on_row_bands(synthetic, test_sky):
     """The benchmark's frame (3840x2160, recursion limit 5, its camera) on all three pipelines: identical frames, and bands
     of rows equal to the oracle's in every plane."""
