@@ -258,6 +258,11 @@ def main():
     sequence = not args.per_frame_calls
     detail = {}
 
+    def progress(msg):
+        """RT_BENCH_PROGRESS=1: phase marks of every rank on stderr (to see where a multi-rank run stands)."""
+        if os.environ.get("RT_BENCH_PROGRESS") == "1":
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     def sync_all():
         torch.cuda.synchronize()
         if use_dist:
@@ -346,22 +351,28 @@ def main():
         timed_frames = [frame_of(k, k + 1) for k in range(steps)]
 
         # untimed: lets the library's selection of pipeline and child order settle on this workload (it times its own first frames)
+        progress(f"{tag}: scene ready")
         if args.pipeline == "auto" or traversal == "auto":
             for k in range(16):
                 if sequence:
                     sc.render_sequence_raw([frame_of(4 * k + j, j + 1) for j in range(4)], target_of(sync=True))
                 else:
                     render(k, k + 1, sync=True)
+        progress(f"{tag}: selection settled on {sc.last_mode()}")
         if warmup:
             run_steps(warm_frames)
+        progress(f"{tag}: warm-up enqueued")
         sync_all()
+        progress(f"{tag}: warm-up done")
         _, _, cand_ms = sc.selection_state()
 
         # the dominant kernel's launches are bracketed with HIP events on their own streams inside the library
         sc.set_kernel_timing(True)
         t0 = time.perf_counter()
         run_steps(timed_frames)
+        progress(f"{tag}: timed steps enqueued")
         sync_all()
+        progress(f"{tag}: timed steps done")
         elapsed = time.perf_counter() - t0
         k_total_ms, k_launches = sc.kernel_time()
         sc.set_kernel_timing(False)
@@ -378,6 +389,7 @@ def main():
         else:
             shown = color
         crc = zlib.crc32(shown.cpu().numpy().tobytes()) if (rank == 0 and shown is not None) else None
+        progress(f"{tag}: frame checksum taken")
 
         # from here on the scene is pinned to what was timed (left alone, the selection looks at the other candidates now and then)
         sc.set_pipeline(pipeline)
@@ -391,7 +403,7 @@ def main():
             n_ser = min(steps, 4)
             ser_frames = [frame_of(k, k + 1) for k in range(n_ser)]
             sc.render_sequence_raw(ser_frames[:2], target_of(sync=True))
-            sync_all()
+            torch.cuda.synchronize()       # (no barrier here: the ranks choose their pipelines independently, and only those on the wavefront pipeline come this way)
             sc.set_kernel_timing(True)
             t1 = time.perf_counter()
             sc.render_sequence_raw(ser_frames, target_of(sync=True))
