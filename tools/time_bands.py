@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Time one rank's share of a 4K frame for several world sizes on one GPU (development aid): part 0 of N interleaved
 16-row bands (RT_TIME_BANDS_ROWS), compact target, issued as rt_render_sequence calls of 16 (RT_TIME_BANDS_SEQ) frames.
-usage: tools/time_bands.py [bunny|s100k|s1m] [max_recursion_limit]"""
+usage: tools/time_bands.py [bunny|s100k|s1m] [max_recursion_limit]
+environment: RT_TIME_BANDS_SIZE=WxH, RT_TIME_BANDS_PARTS=1,2,4,8, RT_TIME_BANDS_CHAINS=<sub-frames>,<frames in flight>,
+RT_TIME_BANDS_STACK=<frames per launch chain>, RT_TIME_BANDS_BATCH=<frames per launch of the one-kernel pipeline> (0: the library's choice)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
