@@ -213,7 +213,8 @@ int rt_scene_set_frames_in_flight(rt_scene *scene, int n);
  * as large: time only enters ray generation (ray_tracer.frag:679), so the first kernel generates the paths of all n frames
  * and the others run unchanged on a queue n times as long, whose sparse end the n frames share.  Samples go to a staging
  * plane per frame and are blended in frame order as above; results are identical.  n = 0 (the default) leaves the number
- * to the library (8, at most 2^25 paths per chain: 4 at 4K).  Not used when the target has planes besides colour.
+ * to the library (8, at most 2^25 paths per chain: 4 at 4K; a chain's workspace is about 112 bytes per path, 3.7 GB at that
+ * cap, and every frame in flight has one).  Not used when the target has planes besides colour.
  * No counterpart in the reference. */
 int rt_scene_set_frames_per_launch(rt_scene *scene, int n);
 /* One-kernel-per-frame pipeline inside rt_render_sequence: when a launch covers only a small part of a 4K frame (one
